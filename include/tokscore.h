@@ -1,0 +1,153 @@
+/*
+ * tokscore.h -- C-ABI of libtokscore.so, the MI355X (gfx950) corpus scorer.
+ *
+ * The reference (asdf2727/tokenizer) is one executable with no plugin or FFI
+ * surface (CMakeLists.txt:8); the seams this library sits behind are C++ member
+ * functions.  Each entry point below names the reference interface it replaces
+ * (paths relative to /root/reference).  Plain pointers and sizes only: no C++
+ * or torch types cross this boundary.  All functions return a TOKSCORE_* status
+ * (the reference reports errors through flags/enums, never exceptions:
+ * src/files/JsonFile.h:17, src/tokenizer/Token.h:13-19).
+ *
+ * Semantics (bit-exact with SolutionFile::Tokenize, src/files/SolutionFile.cpp:83-100):
+ *   - ids: 0 = <START>, 1 = <END>, vocabulary entry i -> id i+2; duplicate strings
+ *     keep the first id; UNKNOWN ((size_t)-1 in the reference) is reported in the
+ *     extra bucket V+2.
+ *   - the corpus is ASCII-lower-cased (A-Z only) before matching, the vocabulary is
+ *     not; matching is on bytes, greedy longest-first, UNKNOWN advances one byte.
+ *   - documents are independent; a document is text bytes [off[d], off[d+1]).
+ *
+ * One context drives one GPU and is not thread-safe; independent contexts are.
+ */
+#ifndef TOKSCORE_H
+#define TOKSCORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+	TOKSCORE_OK = 0,
+	TOKSCORE_E_ARG = 1,        /* null pointer / inconsistent sizes / offsets not monotone */
+	TOKSCORE_E_NO_DEVICE = 2,  /* no usable HIP device: there is NO CPU fallback */
+	TOKSCORE_E_HIP = 3,        /* a HIP runtime call failed (see tokscore_last_error) */
+	TOKSCORE_E_STATE = 4,      /* vocabulary or corpus not set yet */
+	TOKSCORE_E_VOCAB = 5,      /* vocabulary unusable: no non-empty token (the reference
+	                              would loop forever, SolutionFile.cpp:89-97), or too large
+	                              for the packed trie entry (2*slot_bits + id_bits > 64) */
+	TOKSCORE_E_CAPACITY = 6,   /* output buffer too small / internal stream overflow */
+	TOKSCORE_E_INTERNAL = 7
+};
+
+typedef struct tokscore_ctx tokscore_ctx;
+
+/* Library / context --------------------------------------------------------- */
+
+/* ABI version of this header (major*100 + minor). */
+int tokscore_abi_version(void);
+
+/* Number of HIP devices visible (0 when there is no GPU). */
+int tokscore_device_count(void);
+
+/* Create a scorer bound to HIP device `device`.  Fails with TOKSCORE_E_NO_DEVICE
+ * when no GPU is present.  Replaces: constructing the per-process scorer state the
+ * reference keeps in SolutionFile (src/files/SolutionFile.h:9-12). */
+int tokscore_create(tokscore_ctx **out, int device);
+void tokscore_destroy(tokscore_ctx *ctx);
+
+/* Human-readable text for a status code / the last failure inside ctx. */
+const char *tokscore_strerror(int status);
+const char *tokscore_last_error(const tokscore_ctx *ctx);
+
+/* Vocabulary in --------------------------------------------------------------
+ * Replaces SolutionFile(const std::vector<std::string>&, path) /
+ * SolutionFile(path) id assignment (src/files/SolutionFile.cpp:43-72) and the
+ * tokens_ map behind GetId (:74-77).  Token i = bytes[off[i] .. off[i+1]). */
+int tokscore_set_vocab(tokscore_ctx *ctx, const uint8_t *bytes, const uint64_t *off, uint64_t V);
+
+/* max_len_ in BYTES over the whole vocabulary (SolutionFile.cpp:55,68). */
+int tokscore_vocab_max_len(const tokscore_ctx *ctx, uint64_t *max_len);
+
+/* Annealing move on the scored vocabulary: disable / re-enable entry `token_index`
+ * without rebuilding the trie (a disabled entry can never be emitted; duplicates of
+ * its string are not promoted).  There is no reference counterpart on the corpus
+ * path: the reference judges moves on the candidate DAG (src/tokenizer/Token.cpp:83-105);
+ * parity is defined as "equal to a full score with the toggled vocabulary". */
+int tokscore_toggle(tokscore_ctx *ctx, uint64_t token_index, int enable);
+
+/* Corpus in --------------------------------------------------------------------
+ * Replaces DataFile::GetEntries() (src/files/DataFile.cpp:24-31) as the document
+ * source: D documents packed back to back, raw (NOT lower-cased) bytes, document d =
+ * bytes[off[d] .. off[d+1]).  Host buffers; copied to HBM once and kept resident. */
+int tokscore_set_corpus(tokscore_ctx *ctx, const uint8_t *bytes, const uint64_t *off, uint64_t D);
+
+/* Same, for buffers that already live in this device's memory (no copy is made; the
+ * caller keeps them alive and unchanged while the context uses them).  d_bytes must be
+ * readable for 256 bytes past off[D] (the scan prefetches a halo). */
+int tokscore_set_corpus_device(tokscore_ctx *ctx, const void *d_bytes, const void *d_off, uint64_t D,
+                               uint64_t total_bytes);
+
+/* Scoring ----------------------------------------------------------------------
+ * One full-vocabulary evaluation of the resident corpus.  Replaces the loop at
+ * src/main.cpp:38-43 (Tokenize per article, init_size/comp_size accumulation) plus the
+ * histogram of the ids Tokenize returns.
+ *   counts[V+3]   counts[id] for id 0..V+1 (START/END once per document) and
+ *                 counts[V+2] = UNKNOWN emissions
+ *   total_tokens  sum over documents of ids.size() - 2      (main.cpp:41)
+ *   total_bytes   sum over documents of text.size()          (main.cpp:40) */
+int tokscore_score(tokscore_ctx *ctx, uint64_t *counts, uint64_t *total_tokens, uint64_t *total_bytes);
+
+/* Asynchronous form: results stay on the device in d_out[V+5] =
+ * counts[V+3] | total_tokens | total_bytes (the vector a multi-GPU caller all-reduces),
+ * enqueued on `stream` (a hipStream_t, or NULL for the context's own stream). */
+int tokscore_score_async(tokscore_ctx *ctx, void *d_out, void *stream);
+
+/* Re-score after tokscore_toggle calls: identical results to tokscore_score. */
+int tokscore_score_incremental(tokscore_ctx *ctx, uint64_t *counts, uint64_t *total_tokens,
+                               uint64_t *total_bytes);
+
+/* Per-document id sequence, the exact return value of
+ * SolutionFile::Tokenize(std::string) (src/files/SolutionFile.cpp:83-100) for one
+ * document of raw bytes; UNKNOWN is UINT64_MAX as in the reference.  ids_out has room
+ * for `cap` entries (n+2 always suffices); *n_ids receives the count. */
+int tokscore_tokenize(tokscore_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t *ids_out, uint64_t cap,
+                      uint64_t *n_ids);
+
+/* Introspection for benchmarks / profiling -------------------------------------- */
+typedef struct {
+	uint64_t vocab_size;      /* V */
+	uint64_t max_len;         /* bytes */
+	uint64_t trie_nodes;      /* byte-trie nodes incl. root */
+	uint64_t trie_slots;      /* double-array slots (8 B each) */
+	uint64_t trie_lds_slots;  /* slots staged in LDS by the scan kernel */
+	uint64_t corpus_bytes;
+	uint64_t corpus_docs;
+	uint64_t chunks;          /* wave work units of the scan kernel */
+	uint32_t slot_bits;       /* packed entry = parent:slot_bits | base:slot_bits | id:id_bits */
+	uint32_t id_bits;
+	uint32_t scan_path;       /* 1 = LDS tile scan kernel, 0 = generic global-memory scan */
+	uint32_t reserved;
+} tokscore_info;
+int tokscore_get_info(tokscore_ctx *ctx, tokscore_info *info);
+
+/* Time of the last tokscore_score* call's kernels in milliseconds, measured with HIP
+ * events on the stream the kernels ran on: [0] whole evaluation, [1] scan kernel,
+ * [2] boundary fix-up kernels, [3] histogram + reduce kernels. */
+int tokscore_last_timing(tokscore_ctx *ctx, float ms[4]);
+
+/* Host-side self-check of the packed double-array trie (no GPU involved, used by the
+ * CPU test-suite to validate the builder): longest enabled vocabulary entry that is a
+ * prefix of text[0..n).  *len = 0 when none.  Never used by any scoring entry point. */
+int tokscore_hosttrie_longest(tokscore_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t *len,
+                              uint64_t *id);
+
+/* Contexts without a GPU, for the host-side checks above only: set_vocab and
+ * hosttrie_longest work, every scoring call fails with TOKSCORE_E_NO_DEVICE. */
+int tokscore_create_hostonly(tokscore_ctx **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,164 @@
+"""GPU parity: the HIP path (through the C-ABI) against the reference-generated goldens
+and against the CPU oracle on seeded synthetic corpora.  Bit-exact: integer work only."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import tokenizer_amd as ta
+from tokenizer_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _scorer(env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        s = ta.Scorer(0)
+    finally:
+        pass
+    return s, old
+
+
+def _restore(old):
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def _score_with(env, tokens, corpus, off):
+    """Plan parameters are read from the environment when the first score() plans the launch."""
+    s, old = _scorer(env)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        out = s.score()
+        info = s.info()
+        # a second evaluation on the resident corpus must reproduce the first
+        out2 = s.score()
+        assert np.array_equal(out[0], out2[0]) and out[1:] == out2[1:]
+    finally:
+        _restore(old)
+        s.close()
+    return out, info
+
+
+CONFIGS = [
+    {"TOKSCORE_SCAN": "generic", "TOKSCORE_CHUNK": "64"},     # boundary repair on nearly every chunk
+    {"TOKSCORE_SCAN": "generic", "TOKSCORE_CHUNK": "2048"},
+    {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "8192"},
+    {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "300"},       # many mid-document chunk starts
+    {"TOKSCORE_SCAN": "tile", "TOKSCORE_SEG": "132", "TOKSCORE_WAVES": "8"},
+    {"TOKSCORE_SCAN": "tile", "TOKSCORE_LDS_SLOTS": "300"},   # most trie lookups fall through to L2
+]
+
+
+@pytest.mark.parametrize("cfg", range(len(CONFIGS)))
+@pytest.mark.parametrize("case", O.golden_cases())
+def test_score_matches_reference_golden(case, cfg):
+    g = O.load_golden(case)
+    corpus, off = synth.pack_docs(g["docs"])
+    (counts, tt, tb), info = _score_with(CONFIGS[cfg], g["tokens"], corpus, off)
+    exp = g["expected"]
+    assert tb == exp["total_bytes"]
+    assert tt == exp["total_tokens"]
+    bad = np.nonzero(counts != exp["counts_vec"])[0]
+    assert bad.size == 0, (case, CONFIGS[cfg], bad[:10], counts[bad[:10]], exp["counts_vec"][bad[:10]])
+    if CONFIGS[cfg]["TOKSCORE_SCAN"] == "tile":
+        assert info.scan_path == 1, "tile scan was expected to be selected"
+
+
+@pytest.mark.parametrize("case", [c for c in O.golden_cases() if "ids" in O.load_golden(c)["expected"]])
+def test_tokenize_matches_reference_ids(case):
+    g = O.load_golden(case)
+    s = ta.Scorer(0)
+    s.set_vocab(*synth.pack_vocab(g["tokens"]))
+    for d, ids in zip(g["docs"], g["expected"]["ids"]):
+        assert s.tokenize(d) == ids
+    s.close()
+
+
+@pytest.mark.parametrize("kind,nbytes,V", [("wiki", 6_000_000, 32000), ("cjk", 1_500_000, 8000),
+                                            ("utf8", 1_500_000, 20000)])
+def test_score_matches_oracle_on_synthetic(kind, nbytes, V):
+    gen = {"wiki": synth.wiki_like, "cjk": synth.cjk_heavy, "utf8": synth.random_utf8}[kind]
+    corpus, off = gen(nbytes)
+    tokens = synth.build_vocab(corpus[:min(nbytes, 1_000_000)], V)
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    exp_counts, exp_tt, exp_tb = voc.score(corpus, off, threads=8)
+    for cfg in ({"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "generic"}):
+        (counts, tt, tb), info = _score_with(cfg, tokens, corpus, off)
+        assert (tt, tb) == (exp_tt, exp_tb), (kind, cfg)
+        assert np.array_equal(counts, exp_counts), (kind, cfg)
+
+
+def test_wide_vocabulary_uses_32bit_stream():
+    # V + 3 > 32767 forces 32-bit stream entries and two histogram id ranges
+    corpus, off = synth.random_utf8(1_000_000, seed=11, doc_lo=512, doc_hi=100_000)
+    tokens = synth.build_vocab(corpus, 40000)
+    assert len(tokens) > 33000
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    exp = voc.score(corpus, off, threads=8)
+    (counts, tt, tb), info = _score_with({"TOKSCORE_SCAN": "tile"}, tokens, corpus, off)
+    assert info.scan_path == 1
+    assert (tt, tb) == exp[1:]
+    assert np.array_equal(counts, exp[0])
+
+
+def test_empty_and_tiny_corpora():
+    tokens = [b"a", b"b", b"ab"]
+    for docs in ([], [b""], [b"", b"", b""], [b"a"], [b"", b"ab", b"", b"zab"]):
+        corpus, off = synth.pack_docs(docs)
+        voc = O.OracleVocab(*synth.pack_vocab(tokens))
+        exp = voc.score(corpus, off)
+        for cfg in ({"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "generic"}):
+            (counts, tt, tb), _ = _score_with(cfg, tokens, corpus, off)
+            assert (tt, tb) == exp[1:], (docs, cfg)
+            assert np.array_equal(counts, exp[0]), (docs, cfg)
+
+
+def test_long_tokens_fall_back_to_generic_scan():
+    # a token longer than any lane segment cannot use the LDS tile kernel
+    long_tok = b"x" * 1500
+    tokens = [b"x", b"y", long_tok, b"xy"]
+    docs = [b"x" * 4000 + b"y" + b"x" * 1499 + b"yxy", b"xyxy"]
+    corpus, off = synth.pack_docs(docs)
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    exp = voc.score(corpus, off)
+    (counts, tt, tb), info = _score_with({}, tokens, corpus, off)
+    assert info.scan_path == 0
+    assert (tt, tb) == exp[1:] and np.array_equal(counts, exp[0])
+
+
+def test_toggle_equals_full_rescore_of_the_toggled_vocabulary():
+    corpus, off = synth.cjk_heavy(400_000, seed=9)
+    tokens = synth.build_vocab(corpus[:200_000], 3000)
+    V = len(tokens)
+    s = ta.Scorer(0)
+    s.set_vocab(*synth.pack_vocab(tokens))
+    s.set_corpus(corpus, off)
+    base = s.score()
+    rng = np.random.default_rng(5)
+    enabled = np.ones(V, dtype=bool)
+    multi = [i for i, t in enumerate(tokens) if len(t.decode("utf-8")) > 1]
+    for step in range(12):
+        i = int(rng.choice(multi))
+        enabled[i] = not enabled[i]
+        s.toggle(i, bool(enabled[i]))
+        got = s.score(incremental=True)
+        # reference semantics of a disabled entry: a string that can never match
+        # (upper-case survives in the vocabulary but never in the lower-cased input)
+        sub = [t if enabled[k] else b"\x00DISABLED" + str(k).encode() for k, t in enumerate(tokens)]
+        voc = O.OracleVocab(*synth.pack_vocab(sub))
+        exp = voc.score(corpus, off, threads=8)
+        assert got[1:] == exp[1:], step
+        assert np.array_equal(got[0], exp[0]), step
+    for i in np.nonzero(~enabled)[0].tolist():
+        s.toggle(i, True)
+    again = s.score()
+    assert np.array_equal(again[0], base[0]) and again[1:] == base[1:]
+    s.close()

@@ -1,0 +1,191 @@
+"""tokenizer_amd -- MI355X-native corpus scorer for the annealing tokenizer.
+
+Thin ctypes binding over the C-ABI in include/tokscore.h (libtokscore.so, built in-tree
+by tokenizer_amd/csrc/Makefile).  The binding mirrors the reference's scoring seam --
+SolutionFile::{GetId, Tokenize} (/root/reference/src/files/SolutionFile.h:19-28) and the
+accumulation loop of /root/reference/src/main.cpp:31-46 -- and nothing else.  There is no
+CPU fallback: without the HIP library or without a GPU every scoring call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtokscore.so")
+
+OK = 0
+E_ARG, E_NO_DEVICE, E_HIP, E_STATE, E_VOCAB, E_CAPACITY, E_INTERNAL = 1, 2, 3, 4, 5, 6, 7
+UNKNOWN = 2 ** 64 - 1  # (size_t)-1, SolutionFile.cpp:76
+
+_u8p = C.POINTER(C.c_uint8)
+_u64p = C.POINTER(C.c_uint64)
+
+
+class TokscoreInfo(C.Structure):
+    _fields_ = [("vocab_size", C.c_uint64), ("max_len", C.c_uint64), ("trie_nodes", C.c_uint64),
+                ("trie_slots", C.c_uint64), ("trie_lds_slots", C.c_uint64), ("corpus_bytes", C.c_uint64),
+                ("corpus_docs", C.c_uint64), ("chunks", C.c_uint64), ("slot_bits", C.c_uint32),
+                ("id_bits", C.c_uint32), ("scan_path", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+# every symbol include/tokscore.h declares: (name, restype, argtypes)
+_SIGNATURES = [
+    ("tokscore_abi_version", C.c_int, []),
+    ("tokscore_device_count", C.c_int, []),
+    ("tokscore_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    ("tokscore_create_hostonly", C.c_int, [C.POINTER(C.c_void_p)]),
+    ("tokscore_destroy", None, [C.c_void_p]),
+    ("tokscore_strerror", C.c_char_p, [C.c_int]),
+    ("tokscore_last_error", C.c_char_p, [C.c_void_p]),
+    ("tokscore_set_vocab", C.c_int, [C.c_void_p, _u8p, _u64p, C.c_uint64]),
+    ("tokscore_vocab_max_len", C.c_int, [C.c_void_p, _u64p]),
+    ("tokscore_toggle", C.c_int, [C.c_void_p, C.c_uint64, C.c_int]),
+    ("tokscore_set_corpus", C.c_int, [C.c_void_p, _u8p, _u64p, C.c_uint64]),
+    ("tokscore_set_corpus_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+    ("tokscore_score", C.c_int, [C.c_void_p, _u64p, _u64p, _u64p]),
+    ("tokscore_score_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("tokscore_score_incremental", C.c_int, [C.c_void_p, _u64p, _u64p, _u64p]),
+    ("tokscore_tokenize", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, C.c_uint64, _u64p]),
+    ("tokscore_get_info", C.c_int, [C.c_void_p, C.POINTER(TokscoreInfo)]),
+    ("tokscore_last_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    ("tokscore_hosttrie_longest", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u64p]),
+]
+EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+
+_lib = None
+
+
+class TokscoreError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("tokscore status %d: %s" % (status, message))
+        self.status = status
+
+
+def load_library():
+    """dlopen libtokscore.so; raises (loudly) when the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `make -C tokenizer_amd/csrc` "
+                              "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback"
+                              % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, res, args in _SIGNATURES:
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def device_count() -> int:
+    return int(load_library().tokscore_device_count())
+
+
+def _p8(a):
+    return a.ctypes.data_as(_u8p)
+
+
+def _p64(a):
+    return a.ctypes.data_as(_u64p)
+
+
+class Scorer:
+    """One GPU, one vocabulary, one resident corpus (a tokscore_ctx)."""
+
+    def __init__(self, device: int = 0, host_only: bool = False):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        st = self._lib.tokscore_create_hostonly(C.byref(self._h)) if host_only else \
+            self._lib.tokscore_create(C.byref(self._h), device)
+        if st != OK:
+            self._h = None
+            raise TokscoreError(st, self._lib.tokscore_strerror(st).decode())
+        self.V = 0
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tokscore_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, st):
+        if st != OK:
+            msg = self._lib.tokscore_last_error(self._h).decode() or self._lib.tokscore_strerror(st).decode()
+            raise TokscoreError(st, msg)
+
+    # vocabulary -- SolutionFile(tokens, path) id assignment (SolutionFile.cpp:59-72)
+    def set_vocab(self, tok_bytes: np.ndarray, tok_off: np.ndarray):
+        b = np.ascontiguousarray(tok_bytes, dtype=np.uint8)
+        if b.size == 0:
+            b = np.zeros(1, dtype=np.uint8)
+        o = np.ascontiguousarray(tok_off, dtype=np.uint64)
+        self._check(self._lib.tokscore_set_vocab(self._h, _p8(b), _p64(o), len(o) - 1))
+        self.V = len(o) - 1
+
+    def set_vocab_list(self, tokens):
+        from .synth import pack_vocab
+        self.set_vocab(*pack_vocab(tokens))
+
+    @property
+    def max_len(self) -> int:
+        v = C.c_uint64()
+        self._check(self._lib.tokscore_vocab_max_len(self._h, C.byref(v)))
+        return int(v.value)
+
+    def toggle(self, token_index: int, enable: bool):
+        self._check(self._lib.tokscore_toggle(self._h, token_index, 1 if enable else 0))
+
+    # corpus -- DataFile::GetEntries() packed (DataFile.cpp:24-31)
+    def set_corpus(self, corpus: np.ndarray, doc_off: np.ndarray):
+        b = np.ascontiguousarray(corpus, dtype=np.uint8)
+        if b.size == 0:
+            b = np.zeros(1, dtype=np.uint8)
+        o = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        self._check(self._lib.tokscore_set_corpus(self._h, _p8(b), _p64(o), len(o) - 1))
+
+    def set_corpus_device(self, d_bytes_ptr: int, d_off_ptr: int, n_docs: int, total_bytes: int, keep=None):
+        self._keep = [keep]
+        self._check(self._lib.tokscore_set_corpus_device(self._h, d_bytes_ptr, d_off_ptr, n_docs, total_bytes))
+
+    # scoring -- main.cpp:38-43 accumulation + histogram of the ids Tokenize emits
+    def score(self, incremental: bool = False):
+        counts = np.zeros(self.V + 3, dtype=np.uint64)
+        tt = C.c_uint64()
+        tb = C.c_uint64()
+        fn = self._lib.tokscore_score_incremental if incremental else self._lib.tokscore_score
+        self._check(fn(self._h, _p64(counts), C.byref(tt), C.byref(tb)))
+        return counts, int(tt.value), int(tb.value)
+
+    def score_async(self, d_out_ptr: int, stream_ptr: int = 0):
+        self._check(self._lib.tokscore_score_async(self._h, d_out_ptr, stream_ptr))
+
+    # SolutionFile::Tokenize (SolutionFile.cpp:83-100); -1 stands for (size_t)-1
+    def tokenize(self, text: bytes):
+        a = np.frombuffer(text, dtype=np.uint8) if text else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(len(text) + 2, dtype=np.uint64)
+        n = C.c_uint64()
+        self._check(self._lib.tokscore_tokenize(self._h, _p8(a), len(text), _p64(out), len(out), C.byref(n)))
+        return [-1 if int(x) == UNKNOWN else int(x) for x in out[:int(n.value)]]
+
+    def info(self) -> TokscoreInfo:
+        i = TokscoreInfo()
+        self._check(self._lib.tokscore_get_info(self._h, C.byref(i)))
+        return i
+
+    def last_timing(self):
+        ms = (C.c_float * 4)()
+        self._check(self._lib.tokscore_last_timing(self._h, ms))
+        return [float(x) for x in ms]
+
+    def hosttrie_longest(self, text: bytes):
+        a = np.frombuffer(text, dtype=np.uint8) if text else np.zeros(1, dtype=np.uint8)
+        ln = C.c_uint64()
+        tid = C.c_uint64()
+        self._check(self._lib.tokscore_hosttrie_longest(self._h, _p8(a), len(text), C.byref(ln), C.byref(tid)))
+        return int(ln.value), int(tid.value)

@@ -1,0 +1,84 @@
+// device_common.h -- structures and device helpers shared by the gfx950 kernels.
+//
+// All kernels restate SolutionFile::Tokenize (/root/reference/src/files/SolutionFile.cpp:83-100)
+// on a packed byte trie (trie.h): at a position the walk follows lower-cased bytes
+// while children exist and remembers the deepest node that carries an id; that is the
+// reference's "first hit scanning len = min(max_len_, remaining) .. 1" (:90-96).  No id
+// on the path means UNKNOWN and a one-byte advance (:92-94).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tokscore {
+
+struct TrieDev {
+	const uint64_t *slots; // packed double array in HBM (L2-resident in practice)
+	uint32_t nslots;
+	uint32_t slot_bits;
+	uint32_t pmask;      // (1 << slot_bits) - 1
+	uint32_t id_shift;   // 2 * slot_bits
+	uint32_t unknown_id; // V + 2
+	uint32_t lds_slots;  // slots [0, lds_slots) are staged in LDS by the tile scan
+};
+
+struct CorpusDev {
+	const uint8_t *bytes; // raw (not lower-cased) document bytes, back to back
+	const uint64_t *off;  // D + 1 document offsets, off[0] == 0, off[D] == total
+	uint64_t D;
+	uint64_t total;
+};
+
+// Per work-chunk boundary state.  A chunk [begin, end) owns the tokens that START in
+// it.  entry = overshoot (bytes) of the chain coming in from the previous chunk that
+// the chunk's currently counted chain assumed; exit = overshoot past `end` of that
+// chain.  The scan speculates entry = 0; the fix-up kernels repair the rest.
+struct ChunkState {
+	const uint64_t *begin; // nchunks + 1 entries
+	uint32_t *entry;       // assumed entry overshoot of the counted chain
+	uint32_t *exit_a;      // exit overshoot written by the scan
+	uint32_t *exit_b;      // exit overshoot after fix-up
+	uint32_t nchunks;
+};
+
+// std::tolower on unsigned char in the "C" locale: only A-Z (SolutionFile.cpp:87-88).
+__device__ __forceinline__ uint32_t lower8(uint32_t c) { return c + (((c - 65u) < 26u) ? 32u : 0u); }
+
+// Smallest document offset strictly greater than pos (corpus end if none): the walk
+// window is clipped there, as `input.size() - pos` clips it at :90.
+__device__ __forceinline__ uint64_t next_boundary(const CorpusDev &C, uint64_t pos) {
+	uint64_t lo = 0, hi = C.D + 1;
+	while (lo < hi) {
+		const uint64_t mid = (lo + hi) >> 1;
+		if (C.off[mid] > pos) hi = mid;
+		else lo = mid + 1;
+	}
+	return lo <= C.D ? C.off[lo] : C.total;
+}
+
+// One token of the greedy chain, trie and corpus both read from global memory.
+__device__ __forceinline__ void walk_token_global(const TrieDev &T, const uint8_t *bytes, uint64_t pos,
+                                                  uint64_t limit, uint32_t &len, uint32_t &id) {
+	uint32_t node = 0;
+	uint32_t base = (uint32_t)(T.slots[0] >> T.slot_bits) & T.pmask;
+	uint32_t d = 0;
+	len = 0;
+	id = T.unknown_id;
+	while (base != 0 && pos + d < limit) {
+		const uint32_t c = lower8(bytes[pos + d]);
+		const uint32_t t = base + c;
+		const uint64_t e = T.slots[t];
+		if (((uint32_t)e & T.pmask) != node) break;
+		node = t;
+		d++;
+		base = (uint32_t)(e >> T.slot_bits) & T.pmask;
+		const uint32_t tid = (uint32_t)(e >> T.id_shift);
+		if (tid) {
+			len = d;
+			id = tid;
+		}
+	}
+	if (len == 0) len = 1; // UNKNOWN advances one byte (SolutionFile.cpp:92-94)
+}
+
+} // namespace tokscore

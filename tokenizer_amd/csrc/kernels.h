@@ -1,0 +1,38 @@
+// kernels.h -- launch entry points of the gfx950 kernels (host-callable wrappers).
+#pragma once
+
+#include "device_common.h"
+
+namespace tokscore {
+
+// kernels_generic.hip
+void launch_scan_generic(const TrieDev &T, const CorpusDev &C, const ChunkState &S, unsigned long long *counts,
+                         hipStream_t stream);
+void launch_fixup(const TrieDev &T, const CorpusDev &C, const ChunkState &S, unsigned long long *counts,
+                  hipStream_t stream);
+void launch_finalize(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, hipStream_t stream);
+void launch_tokenize_one(const TrieDev &T, const uint8_t *text, uint64_t n, unsigned long long *ids, uint64_t cap,
+                         unsigned long long *n_ids, hipStream_t stream);
+
+// kernels_tile.hip -- LDS tile scan + token-stream histogram
+struct TileScanPlan {
+	uint32_t waves_per_block; // waves (64 lanes) per workgroup
+	uint32_t seg_bytes;       // bytes per lane segment (4 * odd)
+	uint32_t lds_slots;       // trie slots staged in LDS
+	uint32_t lds_bytes;       // dynamic LDS per workgroup
+	uint32_t blocks;          // persistent workgroups
+	uint32_t wide_ids;        // 0: 16-bit stream entries, 1: 32-bit
+};
+struct StreamDev {
+	void *blocks;              // token stream, 1 KiB blocks
+	uint32_t capacity_blocks;
+	uint32_t *cursor;          // [0] blocks handed out, [1] overflow flag, [2] next work chunk
+};
+bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num_cus, TileScanPlan *plan);
+void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S, const StreamDev &Q,
+                      const TileScanPlan &plan, const uint64_t *chunk_first_doc, uint64_t max_len,
+                      hipStream_t stream);
+void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,
+                      uint32_t *slab, uint32_t slab_blocks, hipStream_t stream);
+
+} // namespace tokscore

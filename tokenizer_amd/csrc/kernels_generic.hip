@@ -1,0 +1,190 @@
+// kernels_generic.hip -- global-memory kernels: the generic scan (any token length, any
+// vocabulary the packed trie can hold), the chunk-boundary fix-up, and the finalizer.
+//
+// Exact parallel greedy segmentation.  The reference's loop is serial in `pos`
+// (/root/reference/src/files/SolutionFile.cpp:89-97).  Here every work chunk starts a
+// chain at its own first byte (speculating that the previous chunk's last token ended
+// exactly on the boundary) and counts the tokens that start inside the chunk.  The true
+// chain enters chunk j at begin[j] + exit(j-1).  Two greedy chains over the same bytes
+// coincide from the first position they share, and both land exactly on every document
+// start (a match window is clipped there), so the repair for a wrong guess is a "dual
+// walk": step whichever chain is behind, counting the true chain's tokens +1 and the
+// speculative chain's tokens -1, until they meet or both have left the chunk.  If they
+// never meet inside the chunk its exit overshoot changes and the next chunk's repair is
+// redone in order (fixup_ordered).  All arithmetic is integer; counts are exact.
+#include "kernels.h"
+
+namespace tokscore {
+
+// --- generic scan: one lane per chunk -----------------------------------------------
+__global__ void __launch_bounds__(256) scan_generic_kernel(TrieDev T, CorpusDev C, ChunkState S,
+                                                           unsigned long long *counts) {
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < S.nchunks; j += gridDim.x * blockDim.x) {
+		const uint64_t begin = S.begin[j];
+		const uint64_t end = S.begin[j + 1];
+		uint64_t pos = begin;
+		uint64_t limit = next_boundary(C, pos);
+		while (pos < end) {
+			if (pos >= limit) limit = next_boundary(C, pos);
+			uint32_t len, id;
+			walk_token_global(T, C.bytes, pos, limit, len, id);
+			atomicAdd(&counts[id], 1ull);
+			pos += len;
+		}
+		S.entry[j] = 0;
+		S.exit_a[j] = (uint32_t)(pos - end);
+	}
+}
+
+// Dual walk inside chunk [begin, end): chain A (true, counted +1) starts at pa, chain B
+// (currently counted, now -1) at pb.  Returns true when they met (exit unchanged).
+__device__ bool dual_walk(const TrieDev &T, const CorpusDev &C, uint64_t end, uint64_t pa, uint64_t pb,
+                          unsigned long long *counts, uint64_t *pa_out) {
+	// no document start lies strictly between the chunk start and either entry, so one
+	// clip limit serves both chains until they meet (they meet at the latest there)
+	uint64_t limit = next_boundary(C, pa < pb ? pa : pb);
+	while (pa != pb && (pa < end || pb < end)) {
+		uint32_t len, id;
+		if (pa < pb) {
+			if (pa >= limit) limit = next_boundary(C, pa);
+			walk_token_global(T, C.bytes, pa, limit, len, id);
+			atomicAdd(&counts[id], 1ull);
+			pa += len;
+		} else {
+			if (pb >= limit) limit = next_boundary(C, pb);
+			walk_token_global(T, C.bytes, pb, limit, len, id);
+			atomicAdd(&counts[id], ~0ull); // -1 mod 2^64
+			pb += len;
+		}
+	}
+	*pa_out = pa;
+	return pa == pb;
+}
+
+// --- fix-up, parallel round: every chunk repairs against its predecessor's scan exit --
+__global__ void __launch_bounds__(256) fixup_parallel_kernel(TrieDev T, CorpusDev C, ChunkState S,
+                                                             unsigned long long *counts) {
+	for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < S.nchunks; j += gridDim.x * blockDim.x) {
+		uint32_t ex = S.exit_a[j];
+		if (j > 0) {
+			const uint32_t want = S.exit_a[j - 1];
+			const uint32_t have = S.entry[j];
+			if (want != have) {
+				const uint64_t begin = S.begin[j];
+				const uint64_t end = S.begin[j + 1];
+				uint64_t pa;
+				const bool met = dual_walk(T, C, end, begin + want, begin + have, counts, &pa);
+				if (!met) ex = (uint32_t)(pa - end);
+				S.entry[j] = want;
+			}
+		}
+		S.exit_b[j] = ex;
+	}
+}
+
+// --- fix-up, ordered round: one workgroup sweeps the chunks in order and redoes the
+// repair wherever the predecessor's exit is not the entry the chunk was repaired for
+// (only after a dual walk that never met, e.g. long periodic runs).  Launch with ONE
+// block; every thread reaches every barrier.
+__global__ void __launch_bounds__(1024) fixup_ordered_kernel(TrieDev T, CorpusDev C, ChunkState S,
+                                                             unsigned long long *counts) {
+	__shared__ uint32_t s_first;
+	for (uint32_t base = 1; base < S.nchunks; base += blockDim.x) {
+		for (;;) {
+			const uint32_t j = base + threadIdx.x;
+			const bool need = j < S.nchunks && S.exit_b[j - 1] != S.entry[j];
+			if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+			__syncthreads();
+			if (need) atomicMin(&s_first, j);
+			__syncthreads();
+			const uint32_t first = s_first;
+			if (first == 0xFFFFFFFFu) break; // uniform: s_first is read after the barrier
+			if (j == first) {
+				const uint32_t want = S.exit_b[j - 1];
+				const uint32_t have = S.entry[j];
+				const uint64_t begin = S.begin[j];
+				const uint64_t end = S.begin[j + 1];
+				uint64_t pa;
+				const bool met = dual_walk(T, C, end, begin + want, begin + have, counts, &pa);
+				if (!met) S.exit_b[j] = (uint32_t)(pa - end);
+				S.entry[j] = want;
+				__threadfence();
+			}
+			__syncthreads();
+		}
+		__syncthreads();
+	}
+}
+
+// --- finalize: START/END once per document, totals (main.cpp:40-41) -------------------
+// out = counts[V+3] | total_tokens | total_bytes.  One block.
+__global__ void __launch_bounds__(1024) finalize_kernel(unsigned long long *out, uint32_t V, uint64_t D,
+                                                        uint64_t total_bytes) {
+	__shared__ unsigned long long s_part[16];
+	unsigned long long sum = 0;
+	for (uint32_t i = 2 + threadIdx.x; i < V + 3; i += blockDim.x) sum += out[i];
+	for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned long long t = 0;
+		for (uint32_t w = 0; w < (blockDim.x + 63) / 64; w++) t += s_part[w];
+		out[0] = D; // <START> (SolutionFile.cpp:85)
+		out[1] = D; // <END>   (SolutionFile.cpp:98)
+		out[V + 3] = t;
+		out[V + 4] = total_bytes;
+	}
+}
+
+// --- per-document id sequence (the return value of Tokenize) --------------------------
+// One wave; lane 0 walks the chain.  Debug / REPL sized inputs only (main.cpp:48-55).
+__global__ void tokenize_one_kernel(TrieDev T, const uint8_t *text, uint64_t n, unsigned long long *ids,
+                                    uint64_t cap, unsigned long long *n_ids) {
+	if (threadIdx.x != 0 || blockIdx.x != 0) return;
+	uint64_t k = 0;
+	if (k < cap) ids[k] = 0; // <START>
+	k++;
+	uint64_t pos = 0;
+	while (pos < n) {
+		uint32_t len, id;
+		walk_token_global(T, text, pos, n, len, id);
+		if (k < cap) ids[k] = (id == T.unknown_id) ? ~0ull : (unsigned long long)id;
+		k++;
+		pos += len;
+	}
+	if (k < cap) ids[k] = 1; // <END>
+	k++;
+	*n_ids = k;
+}
+
+// --- host launchers ----------------------------------------------------------------------
+static inline uint32_t grid_for(uint32_t n, uint32_t block, uint32_t cap) {
+	uint32_t g = (n + block - 1) / block;
+	if (g < 1) g = 1;
+	return g > cap ? cap : g;
+}
+
+void launch_scan_generic(const TrieDev &T, const CorpusDev &C, const ChunkState &S, unsigned long long *counts,
+                         hipStream_t stream) {
+	if (S.nchunks == 0) return;
+	hipLaunchKernelGGL(scan_generic_kernel, dim3(grid_for(S.nchunks, 256, 8192)), dim3(256), 0, stream, T, C, S, counts);
+}
+
+void launch_fixup(const TrieDev &T, const CorpusDev &C, const ChunkState &S, unsigned long long *counts,
+                  hipStream_t stream) {
+	if (S.nchunks == 0) return;
+	hipLaunchKernelGGL(fixup_parallel_kernel, dim3(grid_for(S.nchunks, 256, 8192)), dim3(256), 0, stream, T, C, S, counts);
+	if (S.nchunks > 1)
+		hipLaunchKernelGGL(fixup_ordered_kernel, dim3(1), dim3(1024), 0, stream, T, C, S, counts);
+}
+
+void launch_finalize(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, hipStream_t stream) {
+	hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(1024), 0, stream, out, V, D, total_bytes);
+}
+
+void launch_tokenize_one(const TrieDev &T, const uint8_t *text, uint64_t n, unsigned long long *ids, uint64_t cap,
+                         unsigned long long *n_ids, hipStream_t stream) {
+	hipLaunchKernelGGL(tokenize_one_kernel, dim3(1), dim3(64), 0, stream, T, text, n, ids, cap, n_ids);
+}
+
+} // namespace tokscore

@@ -1,0 +1,518 @@
+// kernels_tile.hip -- the hot path: LDS-tiled exact greedy segmentation for gfx950, plus
+// the token-stream histogram.
+//
+// scan_tile_kernel.  One wave (64 lanes) is an independent worker; the workgroup only
+// shares the LDS copy of the hot trie slots.  A wave pulls work chunks (whole-document
+// aligned where possible) from an atomic counter and streams each chunk through its own
+// LDS tile of 64 segments x S bytes (S = 4 * odd, so the 64 lanes' byte reads fall in
+// distinct banks when they run in step):
+//   load     coalesced 16 B/lane global loads, ASCII lower-casing on the dwords in flight
+//            (SolutionFile.cpp:87-88), next tile prefetched into registers meanwhile;
+//   bounds   document starts inside the tile become a bitmap; a match window is clipped
+//            at the next start (`input.size() - pos`, SolutionFile.cpp:90);
+//   phase 1  every lane walks the greedy chain of its own segment from the segment's
+//            first byte -- one trie step per iteration in one flat loop, so lanes never
+//            wait for each other's token ends -- and appends the ids it emits to the
+//            wave's queue (ballot + prefix count, no atomics);
+//   phase 2  lane k's true entry is lane k-1's exit overshoot.  Lanes whose guess (0) was
+//            wrong dual-walk the true chain (+ entries) against the guessed one (- entries)
+//            until the chains meet; exits that change are settled in lane order.
+// The queue drains to HBM in 1 KiB blocks; hist_kernel turns the stream into counts with
+// a full-vocabulary LDS histogram per workgroup.  Results equal the serial loop exactly.
+#include "kernels.h"
+
+namespace tokscore {
+
+namespace {
+
+constexpr uint32_t kQueueFlush16 = 512; // entries per 1 KiB block, 16-bit ids
+constexpr uint32_t kQueueFlush32 = 256; // entries per 1 KiB block, 32-bit ids
+constexpr uint32_t kNoLimit = 0x7FFFFFFFu;
+
+__device__ __forceinline__ void wave_sync() {
+	// LDS is in order per wave; this only stops the compiler moving LDS accesses across.
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+// A-Z -> a-z on four packed bytes (bytes >= 0x80 untouched).
+__device__ __forceinline__ uint32_t lower4(uint32_t x) {
+	const uint32_t low7 = x & 0x7F7F7F7Fu;
+	const uint32_t ge_A = low7 + 0x3F3F3F3Fu; // bit7 set iff low7 >= 'A' (0x41)
+	const uint32_t gt_Z = low7 + 0x25252525u; // bit7 set iff low7 >  'Z' (0x5A)
+	const uint32_t is_up = ge_A & ~gt_Z & ~x & 0x80808080u;
+	return x | (is_up >> 2); // + 0x20
+}
+
+template <bool WIDE> struct QTraits;
+template <> struct QTraits<false> {
+	using entry_t = uint16_t;
+	static constexpr uint32_t flush = kQueueFlush16;
+	static constexpr uint32_t neg = 0x8000u;
+	static constexpr uint32_t null_entry = 0x7FFFu;
+};
+template <> struct QTraits<true> {
+	using entry_t = uint32_t;
+	static constexpr uint32_t flush = kQueueFlush32;
+	static constexpr uint32_t neg = 0x80000000u;
+	static constexpr uint32_t null_entry = 0x7FFFFFFFu;
+};
+
+struct WaveCtx {
+	const uint64_t *lds_trie;
+	const uint8_t *tile;   // LDS, tile-relative byte offsets
+	const uint32_t *bitmap; // LDS, bit i = a document starts at tile byte i
+	uint32_t lds_slots;
+	uint32_t root_base;
+};
+
+// next document start strictly after pos, looked up to `stop` (exclusive)
+__device__ __forceinline__ uint32_t find_limit(const uint32_t *bm, uint32_t pos, uint32_t stop) {
+	const uint32_t i = pos + 1;
+	uint32_t w = i >> 5;
+	uint32_t word = bm[w] >> (i & 31);
+	if (word) return i + __builtin_ctz(word);
+	for (w = w + 1; (w << 5) < stop; w++) {
+		word = bm[w];
+		if (word) return (w << 5) + __builtin_ctz(word);
+	}
+	return kNoLimit;
+}
+
+template <bool WIDE> struct Queue {
+	using Q = QTraits<WIDE>;
+	typename Q::entry_t *buf; // LDS, wave private
+	uint32_t count;           // wave uniform
+
+	__device__ __forceinline__ void flush_block(const StreamDev &S, uint32_t lane) {
+		uint32_t blk = 0;
+		if (lane == 0) blk = atomicAdd(&S.cursor[0], 1u);
+		blk = __builtin_amdgcn_readfirstlane(blk);
+		wave_sync();
+		if (blk < S.capacity_blocks) {
+			const uint4 v = reinterpret_cast<const uint4 *>(buf)[lane];
+			reinterpret_cast<uint4 *>(S.blocks)[(size_t)blk * 64 + lane] = v;
+		} else if (lane == 0) {
+			S.cursor[1] = 1u; // overflow: reported by the host, never silently dropped
+		}
+		wave_sync();
+	}
+
+	// append `val` from every lane with pred set
+	__device__ __forceinline__ void push(bool pred, uint32_t val, const StreamDev &S, uint32_t lane) {
+		const unsigned long long m = __ballot(pred);
+		if (m == 0) return;
+		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
+		if (pred) buf[count + rank] = (typename Q::entry_t)val;
+		count += (uint32_t)__builtin_popcountll(m);
+		if (count >= Q::flush) {
+			flush_block(S, lane);
+			const uint32_t rem = count - Q::flush; // < 64
+			typename Q::entry_t keep = 0;
+			if (lane < rem) keep = buf[Q::flush + lane];
+			wave_sync();
+			if (lane < rem) buf[lane] = keep;
+			wave_sync();
+			count = rem;
+		}
+	}
+
+	__device__ __forceinline__ void finish(const StreamDev &S, uint32_t lane) {
+		if (count == 0) return;
+		for (uint32_t i = count + lane; i < Q::flush; i += 64) buf[i] = (typename Q::entry_t)Q::null_entry;
+		flush_block(S, lane);
+		count = 0;
+	}
+};
+
+// One greedy chain walker state (per lane).
+struct Walker {
+	uint32_t node, base, d, last_len, last_id;
+	__device__ __forceinline__ void reset(uint32_t root_base) {
+		node = 0;
+		base = root_base;
+		d = 0;
+		last_len = 0;
+		last_id = 0;
+	}
+};
+
+// One trie step at tile byte q (or end of token).  Returns true when the token that
+// started at `pos` is complete; then len/id hold it.
+__device__ __forceinline__ bool walk_step(const WaveCtx &W, const TrieDev &T, Walker &w, uint32_t pos, uint32_t limit,
+                                          uint32_t &len, uint32_t &id) {
+	const uint32_t q = pos + w.d;
+	bool hit = false;
+	if (w.base != 0 && q < limit) {
+		const uint32_t c = W.tile[q];
+		const uint32_t t = w.base + c;
+		const uint64_t e = (t < W.lds_slots) ? W.lds_trie[t] : T.slots[t];
+		if (((uint32_t)e & T.pmask) == w.node) {
+			hit = true;
+			w.node = t;
+			w.d++;
+			w.base = (uint32_t)(e >> T.slot_bits) & T.pmask;
+			const uint32_t tid = (uint32_t)(e >> T.id_shift);
+			if (tid) {
+				w.last_len = w.d;
+				w.last_id = tid;
+			}
+		}
+	}
+	if (hit) return false;
+	// SolutionFile.cpp:92-94: nothing matched down to len 1 -> UNKNOWN, advance one byte
+	len = w.last_len ? w.last_len : 1u;
+	id = w.last_len ? w.last_id : T.unknown_id;
+	return true;
+}
+
+template <bool WIDE>
+__global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C, ChunkState S, StreamDev Qd,
+                                                         const uint64_t *chunk_first_doc, uint32_t seg_bytes,
+                                                         uint32_t halo_bytes, uint32_t max_len, uint32_t wave_lds_bytes,
+                                                         uint64_t readable_end) {
+	using Q = QTraits<WIDE>;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = threadIdx.x >> 6;
+
+	// ---- stage the hot trie slots in LDS (shared by the workgroup's waves) ----
+	uint64_t *lds_trie = reinterpret_cast<uint64_t *>(smem);
+	for (uint32_t i = threadIdx.x; i < T.lds_slots; i += blockDim.x) lds_trie[i] = T.slots[i];
+	__syncthreads();
+
+	const uint32_t tile_span = 64 * seg_bytes;                 // bytes owned by one tile
+	const uint32_t tile_cap = tile_span + halo_bytes + 16;      // bytes staged (halo + alignment slack)
+	const uint32_t n_vec = (tile_cap + 15) / 16;                // 16-byte vectors per tile
+	const uint32_t bm_words = (tile_cap + 31) / 32 + 1;
+	unsigned char *wbase = smem + (size_t)T.lds_slots * 8 + (size_t)wave * wave_lds_bytes;
+	unsigned char *tile = wbase;
+	uint32_t *bitmap = reinterpret_cast<uint32_t *>(wbase + n_vec * 16);
+	Queue<WIDE> queue;
+	queue.buf = reinterpret_cast<typename Q::entry_t *>(wbase + n_vec * 16 + ((bm_words * 4 + 15) & ~15u));
+	queue.count = 0;
+
+	WaveCtx W;
+	W.lds_trie = lds_trie;
+	W.tile = tile;
+	W.bitmap = bitmap;
+	W.lds_slots = T.lds_slots;
+	W.root_base = (uint32_t)(lds_trie[0] >> T.slot_bits) & T.pmask;
+
+	constexpr int kMaxVec = 5; // register prefetch depth: up to 5 x 16 B per lane
+	const bool reg_prefetch = n_vec <= 64 * kMaxVec;
+
+	for (;;) {
+		// ---- next work chunk ----
+		uint32_t j = 0;
+		if (lane == 0) j = atomicAdd(&Qd.cursor[2], 1u);
+		j = __builtin_amdgcn_readfirstlane(j);
+		if (j >= S.nchunks) break;
+		const uint64_t begin = S.begin[j];
+		const uint64_t end = S.begin[j + 1];
+		uint64_t di = chunk_first_doc[j]; // index of the first document offset >= begin
+		uint32_t carry = 0;              // entry overshoot of lane 0 (0 = speculated at chunk start)
+		uint32_t chunk_exit = 0;
+
+		uint64_t a0 = begin & ~15ull; // 16-byte aligned tile base
+		uint4 pre[kMaxVec];
+		auto load_tile_regs = [&](uint64_t base_abs) {
+#pragma unroll
+			for (int i = 0; i < kMaxVec; i++) {
+				const uint32_t v = lane + 64 * i;
+				const uint64_t a = base_abs + (uint64_t)v * 16;
+				uint4 x = make_uint4(0, 0, 0, 0);
+				if (v < n_vec && a + 16 <= readable_end) x = *reinterpret_cast<const uint4 *>(C.bytes + a);
+				pre[i] = x;
+			}
+		};
+		if (reg_prefetch) load_tile_regs(a0);
+
+		while (a0 < end) {
+			// ---- tile bytes -> LDS (lower-cased) ----
+			wave_sync();
+			if (reg_prefetch) {
+#pragma unroll
+				for (int i = 0; i < kMaxVec; i++) {
+					const uint32_t v = lane + 64 * i;
+					if (v < n_vec) {
+						uint4 x = pre[i];
+						x.x = lower4(x.x);
+						x.y = lower4(x.y);
+						x.z = lower4(x.z);
+						x.w = lower4(x.w);
+						reinterpret_cast<uint4 *>(tile)[v] = x;
+					}
+				}
+				const uint64_t next_a0 = a0 + tile_span;
+				if (next_a0 < end) load_tile_regs(next_a0); // in flight while this tile is walked
+			} else {
+				for (uint32_t v = lane; v < n_vec; v += 64) {
+					const uint64_t a = a0 + (uint64_t)v * 16;
+					uint4 x = make_uint4(0, 0, 0, 0);
+					if (a + 16 <= readable_end) x = *reinterpret_cast<const uint4 *>(C.bytes + a);
+					x.x = lower4(x.x);
+					x.y = lower4(x.y);
+					x.z = lower4(x.z);
+					x.w = lower4(x.w);
+					reinterpret_cast<uint4 *>(tile)[v] = x;
+				}
+			}
+			// ---- document-start bitmap ----
+			for (uint32_t w = lane; w < bm_words; w += 64) bitmap[w] = 0;
+			wave_sync();
+			{
+				// offsets are sorted, so the ones inside [a0, a0 + tile_cap) are a run starting at
+				// di; di itself advances to the first offset at/after the NEXT tile's base
+				const uint64_t tile_end_abs = a0 + tile_cap;
+				const uint64_t next_abs = a0 + tile_span;
+				uint64_t scan = di;
+				bool di_done = false;
+				for (;;) {
+					const uint64_t idx = scan + lane;
+					uint64_t o = ~0ull;
+					if (idx <= C.D) o = C.off[idx];
+					const bool in_tile = o < tile_end_abs; // o >= begin >= a0 because idx >= di
+					if (in_tile) {
+						const uint32_t b = (uint32_t)(o - a0);
+						atomicOr(&bitmap[b >> 5], 1u << (b & 31));
+					}
+					if (!di_done) {
+						const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(o < next_abs));
+						di += cnt;
+						di_done = cnt < 64;
+					}
+					if (__ballot(in_tile) != ~0ull) break;
+					scan += 64;
+				}
+			}
+			wave_sync();
+
+			// ---- phase 1: speculative chain per lane segment ----
+			const uint32_t off0 = (uint32_t)(begin > a0 ? begin - a0 : 0); // only the chunk's first tile
+			const uint64_t rem = end - a0;
+			const uint32_t tile_hi = rem < tile_span ? (uint32_t)rem : tile_span;
+			const uint32_t seg_nom = lane * seg_bytes;
+			uint32_t seg_lo = seg_nom > off0 ? seg_nom : off0;
+			uint32_t seg_hi = seg_nom + seg_bytes < tile_hi ? seg_nom + seg_bytes : tile_hi;
+			const bool nonempty = seg_lo < seg_hi;
+			if (!nonempty) seg_hi = seg_lo;
+			const uint32_t stop = seg_hi + max_len; // no walk of this segment reads at/after stop
+			uint32_t cur_entry = (lane == 0) ? carry : 0u;
+			uint32_t pos = seg_lo + ((lane == 0) ? carry : 0u);
+			uint32_t limit = kNoLimit;
+			Walker wk;
+			wk.reset(W.root_base);
+			bool active = nonempty && pos < seg_hi;
+			if (active) limit = find_limit(bitmap, pos, stop);
+			while (__ballot(active)) {
+				bool done = false;
+				uint32_t len = 0, id = 0;
+				if (active) done = walk_step(W, T, wk, pos, limit, len, id);
+				queue.push(done, id, Qd, lane);
+				if (done) {
+					pos += len;
+					wk.reset(W.root_base);
+					active = pos < seg_hi;
+					if (active && pos >= limit) limit = find_limit(bitmap, pos, stop);
+				}
+			}
+			uint32_t cur_exit = nonempty ? pos - seg_hi : 0u;
+
+			// ---- phase 2: settle entries in lane order ----
+			bool first_round = true;
+			for (;;) {
+				uint32_t want = __shfl_up(cur_exit, 1, 64);
+				if (lane == 0) want = cur_entry;
+				const bool need = nonempty && want != cur_entry;
+				unsigned long long m = __ballot(need);
+				if (m == 0) break;
+				// first round: every lane repairs against its neighbour's speculative exit
+				// in parallel (the common case ends here); afterwards strictly in order.
+				const bool mine = first_round ? need : (lane == (uint32_t)__builtin_ctzll(m));
+				first_round = false;
+				uint32_t pa = seg_nom + want;      // true chain  (+)
+				uint32_t pb = seg_nom + cur_entry; // counted chain (-)
+				bool walking = mine && (pa < seg_hi || pb < seg_hi);
+				bool on_a = pa < pb;
+				uint32_t lim2 = kNoLimit;
+				if (walking) lim2 = find_limit(bitmap, on_a ? pa : pb, stop);
+				wk.reset(W.root_base);
+				while (__ballot(walking)) {
+					bool done = false;
+					uint32_t len = 0, id = 0;
+					if (walking) done = walk_step(W, T, wk, on_a ? pa : pb, lim2, len, id);
+					queue.push(done, on_a ? id : (id | Q::neg), Qd, lane);
+					if (done) {
+						if (on_a) pa += len;
+						else pb += len;
+						wk.reset(W.root_base);
+						walking = pa != pb && (pa < seg_hi || pb < seg_hi);
+						on_a = pa < pb;
+						const uint32_t p = on_a ? pa : pb;
+						if (walking && p >= lim2) lim2 = find_limit(bitmap, p, stop);
+					}
+				}
+				if (mine) {
+					cur_entry = want;
+					if (pa != pb) cur_exit = pa - seg_hi; // never met: the exit moved
+				}
+			}
+
+			// ---- carry into the next tile / chunk exit ----
+			const unsigned long long ne = __ballot(nonempty);
+			const uint32_t last = 63u - (uint32_t)__builtin_clzll(ne); // lane 0 is always non-empty
+			chunk_exit = __shfl(cur_exit, last, 64);
+			carry = chunk_exit;
+			a0 += tile_span;
+		}
+		if (lane == 0) {
+			S.entry[j] = 0;
+			S.exit_a[j] = chunk_exit;
+		}
+	}
+	queue.finish(Qd, lane);
+}
+
+// ---- token stream -> counts ------------------------------------------------------------
+// grid = (slab_blocks, id_ranges); each workgroup keeps int32 bins for its id range in LDS,
+// consumes its share of the 1 KiB stream blocks, then stores the bins to its slab row.
+template <bool WIDE>
+__global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids, uint32_t range_ids, uint32_t *slab) {
+	using Q = QTraits<WIDE>;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	uint32_t *bins = reinterpret_cast<uint32_t *>(smem);
+	const uint32_t lo = blockIdx.y * range_ids;
+	const uint32_t hi = lo + range_ids < n_ids ? lo + range_ids : n_ids;
+	const uint32_t width = hi - lo;
+	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) bins[i] = 0;
+	__syncthreads();
+	uint32_t used = Qd.cursor[0];
+	if (used > Qd.capacity_blocks) used = Qd.capacity_blocks;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t waves = blockDim.x >> 6;
+	const uint4 *blocks = reinterpret_cast<const uint4 *>(Qd.blocks);
+	for (uint32_t b = blockIdx.x * waves + (threadIdx.x >> 6); b < used; b += gridDim.x * waves) {
+		const uint4 v = blocks[(size_t)b * 64 + lane];
+		const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			if (WIDE) {
+				const uint32_t e = wds[k];
+				const uint32_t id = e & 0x7FFFFFFFu;
+				if (id != Q::null_entry && id >= lo && id < hi) atomicAdd(&bins[id - lo], (e & Q::neg) ? 0xFFFFFFFFu : 1u);
+			} else {
+#pragma unroll
+				for (int h = 0; h < 2; h++) {
+					const uint32_t e = (wds[k] >> (16 * h)) & 0xFFFFu;
+					const uint32_t id = e & 0x7FFFu;
+					if (id != Q::null_entry && id >= lo && id < hi) atomicAdd(&bins[id - lo], (e & Q::neg) ? 0xFFFFFFFFu : 1u);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	uint32_t *row = slab + (size_t)blockIdx.x * n_ids + lo;
+	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) row[i] = bins[i];
+}
+
+// counts[id] += sum over slab rows (int32 partials, sign-extended)
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const uint32_t *slab, uint32_t rows, uint32_t n_ids,
+                                                          unsigned long long *counts) {
+	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= n_ids) return;
+	long long sum = 0;
+	for (uint32_t r = 0; r < rows; r++) sum += (long long)(int32_t)slab[(size_t)r * n_ids + id];
+	counts[id] += (unsigned long long)sum;
+}
+
+} // namespace
+
+// ---- host side -----------------------------------------------------------------------------
+
+bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num_cus, TileScanPlan *plan) {
+	static const uint32_t kSeg[] = {68, 132, 260, 516, 1028};
+	uint32_t seg = 0;
+	uint32_t want_seg = 68;
+	if (const char *s = getenv("TOKSCORE_SEG")) want_seg = (uint32_t)atoi(s);
+	for (uint32_t s : kSeg) {
+		if (s >= max_len + 4 && s >= want_seg) {
+			seg = s;
+			break;
+		}
+	}
+	if (!seg) return false; // tokens longer than a lane segment: generic scan
+	uint32_t waves = 16;
+	if (const char *s = getenv("TOKSCORE_WAVES")) waves = (uint32_t)atoi(s);
+	if (waves < 1) waves = 1;
+	if (waves > 16) waves = 16;
+	const uint32_t wide = (V + 2 >= 0x7FFFu) ? 1u : 0u;
+	const uint32_t halo = (uint32_t)((max_len + 15) & ~15ull);
+	const uint32_t lds_total = 160 * 1024;
+	uint32_t wave_bytes = 0;
+	for (;;) {
+		const uint32_t tile_cap = 64 * seg + halo + 16;
+		const uint32_t n_vec = (tile_cap + 15) / 16;
+		const uint32_t bm_words = (tile_cap + 31) / 32 + 1;
+		const uint32_t q_entries = (wide ? kQueueFlush32 : kQueueFlush16) + 64;
+		wave_bytes = n_vec * 16 + ((bm_words * 4 + 15) & ~15u) + ((q_entries * (wide ? 4 : 2) + 15) & ~15u);
+		if ((uint64_t)wave_bytes * waves + 8 * 1024 <= lds_total) break;
+		if (waves == 1) return false;
+		waves >>= 1; // long segments: fewer waves so that the tiles still fit
+	}
+	uint32_t lds_slots = (lds_total - wave_bytes * waves) / 8;
+	if (const char *s = getenv("TOKSCORE_LDS_SLOTS")) lds_slots = std::min<uint32_t>(lds_slots, (uint32_t)atoi(s));
+	if (lds_slots > T.nslots) lds_slots = T.nslots;
+	if (lds_slots < 1) lds_slots = 1;
+	plan->waves_per_block = waves;
+	plan->seg_bytes = seg;
+	plan->lds_slots = lds_slots;
+	plan->lds_bytes = lds_slots * 8 + wave_bytes * waves;
+	plan->blocks = num_cus;
+	plan->wide_ids = wide;
+	return true;
+}
+
+void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S, const StreamDev &Q,
+                      const TileScanPlan &plan, const uint64_t *chunk_first_doc, uint64_t max_len,
+                      hipStream_t stream) {
+	const uint32_t halo = (uint32_t)((max_len + 15) & ~15ull);
+	const uint32_t wave_bytes = (plan.lds_bytes - plan.lds_slots * 8) / plan.waves_per_block;
+	const uint64_t readable_end = (C.total + 256) & ~15ull;
+	TrieDev Tl = T;
+	Tl.lds_slots = plan.lds_slots;
+	if (plan.wide_ids) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_tile_kernel<true>),
+		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+		hipLaunchKernelGGL(scan_tile_kernel<true>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes,
+		                   stream, Tl, C, S, Q, chunk_first_doc, plan.seg_bytes, halo, (uint32_t)max_len, wave_bytes,
+		                   readable_end);
+	} else {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_tile_kernel<false>),
+		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+		hipLaunchKernelGGL(scan_tile_kernel<false>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes,
+		                   stream, Tl, C, S, Q, chunk_first_doc, plan.seg_bytes, halo, (uint32_t)max_len, wave_bytes,
+		                   readable_end);
+	}
+}
+
+void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,
+                      uint32_t *slab, uint32_t slab_blocks, hipStream_t stream) {
+	const uint32_t n_ids = V + 3;
+	const uint32_t range = std::min<uint32_t>(n_ids, 32768);
+	const uint32_t ranges = (n_ids + range - 1) / range;
+	const uint32_t lds = range * 4;
+	if (plan.wide_ids) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_kernel<true>),
+		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(hist_kernel<true>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab);
+	} else {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_kernel<false>),
+		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(hist_kernel<false>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab);
+	}
+	hipLaunchKernelGGL(slab_reduce_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, stream, slab, slab_blocks, n_ids,
+	                   counts);
+}
+
+} // namespace tokscore

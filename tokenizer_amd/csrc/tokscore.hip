@@ -1,0 +1,606 @@
+// tokscore.hip -- C-ABI of libtokscore.so (include/tokscore.h): context, HBM residency,
+// chunk planning and kernel sequencing.  There is no CPU scoring path in this library:
+// without a HIP device every scoring entry point fails with TOKSCORE_E_NO_DEVICE.
+#include "../../include/tokscore.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "trie.h"
+
+using namespace tokscore;
+
+namespace {
+
+constexpr uint64_t kCorpusPad = 4096;         // readable zero bytes past the corpus end (tile halo)
+constexpr uint64_t kSampleBytes = 2u << 20;   // host sample for the hot-first trie layout
+constexpr uint64_t kSamplePieces = 16;
+
+uint64_t env_u64(const char *name, uint64_t dflt) {
+	const char *s = getenv(name);
+	if (!s || !*s) return dflt;
+	return strtoull(s, nullptr, 10);
+}
+
+} // namespace
+
+struct tokscore_ctx {
+	bool hostonly = false;
+	int device = -1;
+	int num_cus = 256;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[5] = {};
+	std::string err;
+
+	// vocabulary
+	VocabTrie trie;
+	PackedTrie packed;
+	bool vocab_set = false;
+	bool packed_valid = false;  // host image matches trie + hotness
+	bool device_trie_valid = false;
+	uint64_t *d_slots = nullptr;
+	uint64_t d_slots_cap = 0;
+	uint64_t V = 0;
+
+	// corpus
+	bool corpus_set = false;
+	bool own_corpus = false;
+	uint8_t *d_bytes = nullptr;
+	uint64_t *d_off = nullptr;
+	uint64_t D = 0;
+	uint64_t total = 0;
+	std::vector<uint64_t> h_off;
+	std::vector<uint8_t> sample;
+	bool sample_used = false;
+
+	// plan
+	bool plan_valid = false;
+	int scan_path = 0; // 0 generic, 1 tile
+	TileScanPlan tile = {};
+	uint64_t chunk_bytes = 0;
+	std::vector<uint64_t> h_chunk_begin;
+	uint64_t *d_chunk_begin = nullptr;
+	uint64_t *d_chunk_first_doc = nullptr;
+	uint32_t *d_chunk_state = nullptr; // entry | exit_a | exit_b
+	uint32_t nchunks = 0;
+	void *d_stream = nullptr;
+	uint32_t stream_cap_blocks = 0;
+	uint32_t *d_cursor = nullptr;
+	uint32_t *d_slab = nullptr;
+	uint32_t slab_blocks = 0;
+
+	// outputs
+	unsigned long long *d_out = nullptr;
+	uint64_t d_out_cap = 0;
+	float last_ms[4] = {0, 0, 0, 0};
+	bool timing_pending = false;
+};
+
+namespace {
+
+int fail(tokscore_ctx *c, int status, const std::string &msg) {
+	if (c) c->err = msg;
+	return status;
+}
+
+#define HIP_TRY(ctx, call)                                                                              \
+	do {                                                                                                \
+		hipError_t _e = (call);                                                                         \
+		if (_e != hipSuccess)                                                                           \
+			return fail(ctx, TOKSCORE_E_HIP, std::string(#call) + ": " + hipGetErrorString(_e));        \
+	} while (0)
+
+void free_corpus(tokscore_ctx *c) {
+	if (c->own_corpus) {
+		if (c->d_bytes) (void)hipFree(c->d_bytes);
+		if (c->d_off) (void)hipFree(c->d_off);
+	}
+	c->d_bytes = nullptr;
+	c->d_off = nullptr;
+	c->own_corpus = false;
+	c->corpus_set = false;
+	c->plan_valid = false;
+}
+
+void free_plan(tokscore_ctx *c) {
+	if (c->d_chunk_begin) (void)hipFree(c->d_chunk_begin);
+	if (c->d_chunk_state) (void)hipFree(c->d_chunk_state);
+	if (c->d_chunk_first_doc) (void)hipFree(c->d_chunk_first_doc);
+	c->d_chunk_first_doc = nullptr;
+	if (c->d_stream) (void)hipFree(c->d_stream);
+	if (c->d_cursor) (void)hipFree(c->d_cursor);
+	if (c->d_slab) (void)hipFree(c->d_slab);
+	c->d_chunk_begin = nullptr;
+	c->d_chunk_state = nullptr;
+	c->d_stream = nullptr;
+	c->d_cursor = nullptr;
+	c->d_slab = nullptr;
+	c->plan_valid = false;
+}
+
+// Work chunks: cut every ~chunk_bytes, snapped forward to a document start when one is
+// within half a chunk (then the chunk's entry is certain and needs no repair) -- the
+// same unit of independence the reference parallelises over (main.cpp:38-43).  Long
+// documents are cut mid-text and repaired by the fix-up kernels.
+void build_chunks(tokscore_ctx *c, uint64_t chunk_bytes) {
+	std::vector<uint64_t> &b = c->h_chunk_begin;
+	b.clear();
+	b.push_back(0);
+	const std::vector<uint64_t> &off = c->h_off;
+	uint64_t pos = 0;
+	while (pos + chunk_bytes + chunk_bytes / 2 < c->total) {
+		const uint64_t target = pos + chunk_bytes;
+		auto it = std::lower_bound(off.begin(), off.end(), target);
+		uint64_t next = target;
+		if (it != off.end() && *it - target <= chunk_bytes / 2 && *it < c->total) next = *it;
+		b.push_back(next);
+		pos = next;
+	}
+	b.push_back(c->total);
+}
+
+TrieDev trie_dev(const tokscore_ctx *c) {
+	TrieDev T;
+	T.slots = c->d_slots;
+	T.nslots = (uint32_t)c->packed.slots.size();
+	T.slot_bits = c->packed.slot_bits;
+	T.pmask = c->packed.pmask();
+	T.id_shift = 2 * c->packed.slot_bits;
+	T.unknown_id = c->packed.unknown_id;
+	T.lds_slots = c->tile.lds_slots;
+	return T;
+}
+
+int ensure_trie(tokscore_ctx *c) {
+	if (!c->vocab_set) return fail(c, TOKSCORE_E_STATE, "vocabulary not set");
+	if (!c->packed_valid || (!c->sample_used && !c->sample.empty())) {
+		if (!c->sample.empty() && !c->sample_used) {
+			c->trie.AddHotnessSample(c->sample.data(), c->sample.size());
+			c->sample_used = true;
+		}
+		std::string e;
+		if (!c->trie.Pack(&c->packed, &e)) return fail(c, TOKSCORE_E_VOCAB, e);
+		c->packed_valid = true;
+		c->device_trie_valid = false;
+		c->plan_valid = false;
+	}
+	if (c->hostonly) return TOKSCORE_OK;
+	if (!c->device_trie_valid) {
+		const uint64_t n = c->packed.slots.size();
+		if (n > c->d_slots_cap) {
+			if (c->d_slots) (void)hipFree(c->d_slots);
+			c->d_slots = nullptr;
+			HIP_TRY(c, hipMalloc((void **)&c->d_slots, n * sizeof(uint64_t)));
+			c->d_slots_cap = n;
+		}
+		HIP_TRY(c, hipMemcpyAsync(c->d_slots, c->packed.slots.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice,
+		                          c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+		c->device_trie_valid = true;
+	}
+	return TOKSCORE_OK;
+}
+
+int ensure_plan(tokscore_ctx *c) {
+	if (c->plan_valid) return TOKSCORE_OK;
+	free_plan(c);
+	const char *force = getenv("TOKSCORE_SCAN");
+	TrieDev T = trie_dev(c);
+	bool tile_ok = plan_tile_scan(T, c->packed.max_len, (uint32_t)c->V, (uint32_t)c->num_cus, &c->tile);
+	if (force && !strcmp(force, "generic")) tile_ok = false;
+	c->scan_path = tile_ok ? 1 : 0;
+	if (!tile_ok) c->tile = TileScanPlan{};
+	uint64_t dflt_chunk = 2048;
+	if (tile_ok) {
+		// a few chunks per resident wave, so the atomic work queue can balance the tail
+		const uint64_t waves = (uint64_t)c->tile.blocks * c->tile.waves_per_block;
+		dflt_chunk = std::min<uint64_t>(64u * 1024u, std::max<uint64_t>(8u * 1024u, c->total / (waves * 4)));
+	}
+	c->chunk_bytes = env_u64("TOKSCORE_CHUNK", dflt_chunk);
+	if (c->chunk_bytes < 64) c->chunk_bytes = 64;
+	if (c->chunk_bytes < 4 * c->packed.max_len) c->chunk_bytes = 4 * c->packed.max_len;
+	build_chunks(c, c->chunk_bytes);
+	c->nchunks = (uint32_t)(c->h_chunk_begin.size() - 1);
+	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_begin, c->h_chunk_begin.size() * sizeof(uint64_t)));
+	HIP_TRY(c, hipMemcpy(c->d_chunk_begin, c->h_chunk_begin.data(), c->h_chunk_begin.size() * sizeof(uint64_t),
+	                     hipMemcpyHostToDevice));
+	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_state, (size_t)3 * (c->nchunks + 1) * sizeof(uint32_t)));
+	{
+		std::vector<uint64_t> first(c->nchunks + 1);
+		for (uint32_t j = 0; j <= c->nchunks; j++)
+			first[j] = (uint64_t)(std::lower_bound(c->h_off.begin(), c->h_off.end(), c->h_chunk_begin[j]) - c->h_off.begin());
+		HIP_TRY(c, hipMalloc((void **)&c->d_chunk_first_doc, first.size() * sizeof(uint64_t)));
+		HIP_TRY(c, hipMemcpy(c->d_chunk_first_doc, first.data(), first.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+	}
+	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, 64));
+	if (c->scan_path == 1) {
+		// Token stream: <= 1 entry per corpus byte from the speculative pass, <= 2 per byte
+		// from the parallel repair round and <= 2 per byte from the ordered round, plus one
+		// partly filled 1 KiB block per wave.
+		const uint64_t entry_bytes = c->tile.wide_ids ? 4 : 2;
+		const uint64_t entries = 5 * c->total + 1024;
+		const uint64_t waves = (uint64_t)c->tile.blocks * c->tile.waves_per_block;
+		const uint64_t blocks = (entries * entry_bytes + 1023) / 1024 + 2 * waves + 16;
+		if (blocks > 0xFFFFFFF0ull) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one token stream");
+		c->stream_cap_blocks = (uint32_t)blocks;
+		HIP_TRY(c, hipMalloc(&c->d_stream, blocks * 1024));
+		c->slab_blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, c->total / (256 * 1024)));
+		HIP_TRY(c, hipMalloc((void **)&c->d_slab, (size_t)c->slab_blocks * (c->V + 3) * sizeof(uint32_t)));
+	}
+	c->plan_valid = true;
+	return TOKSCORE_OK;
+}
+
+int ensure_out(tokscore_ctx *c) {
+	const uint64_t n = c->V + 5;
+	if (n > c->d_out_cap) {
+		if (c->d_out) (void)hipFree(c->d_out);
+		c->d_out = nullptr;
+		HIP_TRY(c, hipMalloc((void **)&c->d_out, n * sizeof(unsigned long long)));
+		c->d_out_cap = n;
+	}
+	return TOKSCORE_OK;
+}
+
+// Enqueue one full evaluation into d_out (V+5 u64) on stream s.
+int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
+	int st = ensure_trie(c);
+	if (st) return st;
+	if (!c->corpus_set) return fail(c, TOKSCORE_E_STATE, "corpus not set");
+	st = ensure_plan(c);
+	if (st) return st;
+	TrieDev T = trie_dev(c);
+	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+	ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
+	             c->d_chunk_state + 2 * (size_t)(c->nchunks + 1), c->nchunks};
+	HIP_TRY(c, hipEventRecord(c->ev[0], s));
+	HIP_TRY(c, hipMemsetAsync(d_out, 0, (c->V + 5) * sizeof(unsigned long long), s));
+	if (c->scan_path == 1) {
+		HIP_TRY(c, hipMemsetAsync(c->d_cursor, 0, 64, s));
+		StreamDev Q{c->d_stream, c->stream_cap_blocks, c->d_cursor};
+		HIP_TRY(c, hipEventRecord(c->ev[1], s));
+		launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s);
+		HIP_TRY(c, hipEventRecord(c->ev[2], s));
+		launch_fixup(T, C, S, d_out, s);
+		HIP_TRY(c, hipEventRecord(c->ev[3], s));
+		launch_histogram(Q, c->tile, (uint32_t)c->V, d_out, c->d_slab, c->slab_blocks, s);
+	} else {
+		HIP_TRY(c, hipEventRecord(c->ev[1], s));
+		launch_scan_generic(T, C, S, d_out, s);
+		HIP_TRY(c, hipEventRecord(c->ev[2], s));
+		launch_fixup(T, C, S, d_out, s);
+		HIP_TRY(c, hipEventRecord(c->ev[3], s));
+	}
+	launch_finalize(d_out, (uint32_t)c->V, c->D, c->total, s);
+	HIP_TRY(c, hipEventRecord(c->ev[4], s));
+	HIP_TRY(c, hipGetLastError());
+	c->timing_pending = true;
+	return TOKSCORE_OK;
+}
+
+int check_overflow(tokscore_ctx *c) {
+	if (c->scan_path != 1) return TOKSCORE_OK;
+	uint32_t cur[2] = {0, 0};
+	HIP_TRY(c, hipMemcpy(cur, c->d_cursor, sizeof cur, hipMemcpyDeviceToHost));
+	if (cur[1]) return fail(c, TOKSCORE_E_CAPACITY, "token stream overflow (internal capacity bound violated)");
+	return TOKSCORE_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int tokscore_abi_version(void) { return 100; }
+
+int tokscore_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+const char *tokscore_strerror(int status) {
+	switch (status) {
+	case TOKSCORE_OK: return "ok";
+	case TOKSCORE_E_ARG: return "invalid argument";
+	case TOKSCORE_E_NO_DEVICE: return "no HIP device (libtokscore has no CPU fallback)";
+	case TOKSCORE_E_HIP: return "HIP runtime error";
+	case TOKSCORE_E_STATE: return "vocabulary or corpus not set";
+	case TOKSCORE_E_VOCAB: return "unusable vocabulary";
+	case TOKSCORE_E_CAPACITY: return "capacity exceeded";
+	case TOKSCORE_E_INTERNAL: return "internal error";
+	}
+	return "unknown status";
+}
+
+const char *tokscore_last_error(const tokscore_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int tokscore_create(tokscore_ctx **out, int device) {
+	if (!out) return TOKSCORE_E_ARG;
+	*out = nullptr;
+	int n = tokscore_device_count();
+	if (n <= 0 || device < 0 || device >= n) return TOKSCORE_E_NO_DEVICE;
+	if (hipSetDevice(device) != hipSuccess) return TOKSCORE_E_NO_DEVICE;
+	tokscore_ctx *c = new tokscore_ctx();
+	c->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+		delete c;
+		return TOKSCORE_E_HIP;
+	}
+	for (auto &e : c->ev) {
+		if (hipEventCreate(&e) != hipSuccess) {
+			delete c;
+			return TOKSCORE_E_HIP;
+		}
+	}
+	*out = c;
+	return TOKSCORE_OK;
+}
+
+int tokscore_create_hostonly(tokscore_ctx **out) {
+	if (!out) return TOKSCORE_E_ARG;
+	tokscore_ctx *c = new tokscore_ctx();
+	c->hostonly = true;
+	*out = c;
+	return TOKSCORE_OK;
+}
+
+void tokscore_destroy(tokscore_ctx *c) {
+	if (!c) return;
+	if (!c->hostonly) {
+		(void)hipSetDevice(c->device);
+		(void)hipStreamSynchronize(c->stream);
+		free_plan(c);
+		free_corpus(c);
+		if (c->d_slots) (void)hipFree(c->d_slots);
+		if (c->d_out) (void)hipFree(c->d_out);
+		for (auto &e : c->ev)
+			if (e) (void)hipEventDestroy(e);
+		if (c->stream) (void)hipStreamDestroy(c->stream);
+	}
+	delete c;
+}
+
+int tokscore_set_vocab(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *off, uint64_t V) {
+	if (!c || !off || (!bytes && V && off[V] != off[0])) return fail(c, TOKSCORE_E_ARG, "null vocabulary buffers");
+	if (V + 5 >= 0xFFFFFFFFull) return fail(c, TOKSCORE_E_VOCAB, "vocabulary too large");
+	static const uint8_t kEmpty = 0;
+	std::string e;
+	c->vocab_set = false;
+	c->packed_valid = false;
+	c->device_trie_valid = false;
+	c->plan_valid = false;
+	if (!c->trie.Build(bytes ? bytes : &kEmpty, off, V, &e)) return fail(c, TOKSCORE_E_VOCAB, e);
+	c->V = V;
+	c->vocab_set = true;
+	c->sample_used = false;
+	return TOKSCORE_OK;
+}
+
+int tokscore_vocab_max_len(const tokscore_ctx *c, uint64_t *max_len) {
+	if (!c || !max_len) return TOKSCORE_E_ARG;
+	if (!c->vocab_set) return TOKSCORE_E_STATE;
+	*max_len = c->trie.max_len();
+	return TOKSCORE_OK;
+}
+
+int tokscore_toggle(tokscore_ctx *c, uint64_t token_index, int enable) {
+	if (!c) return TOKSCORE_E_ARG;
+	if (!c->vocab_set) return fail(c, TOKSCORE_E_STATE, "vocabulary not set");
+	if (token_index >= c->V) return fail(c, TOKSCORE_E_ARG, "token index out of range");
+	if (!c->packed_valid) {
+		int st = ensure_trie(c);
+		if (st) return st;
+	}
+	uint64_t entry = 0;
+	const int64_t slot = c->trie.Toggle(token_index, enable != 0, &c->packed, &entry);
+	if (slot >= 0 && !c->hostonly && c->device_trie_valid) {
+		(void)hipSetDevice(c->device);
+		HIP_TRY(c, hipMemcpyAsync(c->d_slots + slot, &c->packed.slots[slot], sizeof(uint64_t), hipMemcpyHostToDevice,
+		                          c->stream));
+		HIP_TRY(c, hipStreamSynchronize(c->stream));
+	}
+	return TOKSCORE_OK;
+}
+
+static int adopt_offsets(tokscore_ctx *c, const uint64_t *off, uint64_t D) {
+	c->h_off.resize(D + 1);
+	const uint64_t o0 = off[0];
+	for (uint64_t d = 0; d <= D; d++) {
+		if (d && off[d] < off[d - 1]) return fail(c, TOKSCORE_E_ARG, "document offsets are not monotone");
+		c->h_off[d] = off[d] - o0;
+	}
+	c->D = D;
+	c->total = c->h_off[D];
+	return TOKSCORE_OK;
+}
+
+int tokscore_set_corpus(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *off, uint64_t D) {
+	if (!c || !off) return fail(c, TOKSCORE_E_ARG, "null corpus buffers");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	free_plan(c);
+	free_corpus(c);
+	int st = adopt_offsets(c, off, D);
+	if (st) return st;
+	if (c->total && !bytes) return fail(c, TOKSCORE_E_ARG, "null corpus bytes");
+	const uint8_t *src = bytes ? bytes + off[0] : nullptr;
+	HIP_TRY(c, hipMalloc((void **)&c->d_bytes, c->total + kCorpusPad));
+	c->own_corpus = true;
+	HIP_TRY(c, hipMalloc((void **)&c->d_off, (D + 1) * sizeof(uint64_t)));
+	HIP_TRY(c, hipMemsetAsync(c->d_bytes + c->total, 0, kCorpusPad, c->stream));
+	if (c->total) HIP_TRY(c, hipMemcpyAsync(c->d_bytes, src, c->total, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipMemcpyAsync(c->d_off, c->h_off.data(), (D + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+	// strided host sample that steers the hot-first trie layout (never the results)
+	c->sample.clear();
+	if (c->total) {
+		const uint64_t piece = std::min<uint64_t>(kSampleBytes / kSamplePieces, c->total);
+		const uint64_t pieces = std::min<uint64_t>(kSamplePieces, std::max<uint64_t>(1, c->total / piece));
+		for (uint64_t p = 0; p < pieces; p++) {
+			const uint64_t at = (c->total - piece) / std::max<uint64_t>(1, pieces) * p;
+			c->sample.insert(c->sample.end(), src + at, src + at + piece);
+		}
+	}
+	c->sample_used = false;
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	c->corpus_set = true;
+	return TOKSCORE_OK;
+}
+
+int tokscore_set_corpus_device(tokscore_ctx *c, const void *d_bytes, const void *d_off, uint64_t D,
+                               uint64_t total_bytes) {
+	if (!c || !d_off || (!d_bytes && total_bytes)) return fail(c, TOKSCORE_E_ARG, "null corpus buffers");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	free_plan(c);
+	free_corpus(c);
+	std::vector<uint64_t> off(D + 1);
+	HIP_TRY(c, hipMemcpy(off.data(), d_off, (D + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+	if (off[0] != 0 || off[D] != total_bytes) return fail(c, TOKSCORE_E_ARG, "device offsets must run from 0 to total_bytes");
+	int st = adopt_offsets(c, off.data(), D);
+	if (st) return st;
+	c->d_bytes = (uint8_t *)d_bytes;
+	c->d_off = (uint64_t *)d_off;
+	c->own_corpus = false;
+	c->sample.clear();
+	if (c->total) {
+		const uint64_t piece = std::min<uint64_t>(kSampleBytes / kSamplePieces, c->total);
+		const uint64_t pieces = std::min<uint64_t>(kSamplePieces, std::max<uint64_t>(1, c->total / piece));
+		c->sample.resize(piece * pieces);
+		for (uint64_t p = 0; p < pieces; p++) {
+			const uint64_t at = (c->total - piece) / std::max<uint64_t>(1, pieces) * p;
+			HIP_TRY(c, hipMemcpy(c->sample.data() + p * piece, (const uint8_t *)d_bytes + at, piece, hipMemcpyDeviceToHost));
+		}
+	}
+	c->sample_used = false;
+	c->corpus_set = true;
+	return TOKSCORE_OK;
+}
+
+int tokscore_score_async(tokscore_ctx *c, void *d_out, void *stream) {
+	if (!c || !d_out) return fail(c, TOKSCORE_E_ARG, "null output");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	return enqueue_score(c, (unsigned long long *)d_out, stream ? (hipStream_t)stream : c->stream);
+}
+
+int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, uint64_t *total_bytes) {
+	if (!c || !counts) return fail(c, TOKSCORE_E_ARG, "null output");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	int st = ensure_out(c);
+	if (st) return st;
+	st = enqueue_score(c, c->d_out, c->stream);
+	if (st) return st;
+	std::vector<uint64_t> host(c->V + 5);
+	HIP_TRY(c, hipMemcpyAsync(host.data(), c->d_out, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	st = check_overflow(c);
+	if (st) return st;
+	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
+	if (total_tokens) *total_tokens = host[c->V + 3];
+	if (total_bytes) *total_bytes = host[c->V + 4];
+	return TOKSCORE_OK;
+}
+
+int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, uint64_t *total_bytes) {
+	// Toggles patch the resident trie in place (one 8-byte slot each), so a re-score is
+	// a plain evaluation without any rebuild or re-upload.
+	return tokscore_score(c, counts, total_tokens, total_bytes);
+}
+
+int tokscore_tokenize(tokscore_ctx *c, const uint8_t *text, uint64_t n, uint64_t *ids_out, uint64_t cap,
+                      uint64_t *n_ids) {
+	if (!c || !ids_out || !n_ids || (!text && n)) return fail(c, TOKSCORE_E_ARG, "null buffers");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	int st = ensure_trie(c);
+	if (st) return st;
+	uint8_t *d_text = nullptr;
+	unsigned long long *d_ids = nullptr;
+	const uint64_t need = n + 2;
+	HIP_TRY(c, hipMalloc((void **)&d_text, n + 16));
+	hipError_t e = hipMalloc((void **)&d_ids, (need + 1) * sizeof(unsigned long long));
+	if (e != hipSuccess) {
+		(void)hipFree(d_text);
+		return fail(c, TOKSCORE_E_HIP, hipGetErrorString(e));
+	}
+	int status = TOKSCORE_OK;
+	std::vector<uint64_t> host(need + 1);
+	do {
+		if (n && (e = hipMemcpyAsync(d_text, text, n, hipMemcpyHostToDevice, c->stream)) != hipSuccess) break;
+		launch_tokenize_one(trie_dev(c), d_text, n, d_ids, need, d_ids + need, c->stream);
+		if ((e = hipMemcpyAsync(host.data(), d_ids, (need + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
+		e = hipStreamSynchronize(c->stream);
+	} while (0);
+	(void)hipFree(d_text);
+	(void)hipFree(d_ids);
+	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, hipGetErrorString(e));
+	const uint64_t k = host[need];
+	*n_ids = k;
+	if (k > cap) status = fail(c, TOKSCORE_E_CAPACITY, "ids_out too small");
+	memcpy(ids_out, host.data(), std::min(k, cap) * sizeof(uint64_t));
+	return status;
+}
+
+int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
+	if (!c || !info) return TOKSCORE_E_ARG;
+	memset(info, 0, sizeof *info);
+	info->vocab_size = c->V;
+	if (c->vocab_set) {
+		info->max_len = c->trie.max_len();
+		info->trie_nodes = c->trie.node_count();
+	}
+	if (c->packed_valid) {
+		info->trie_slots = c->packed.slots.size();
+		info->slot_bits = c->packed.slot_bits;
+		info->id_bits = c->packed.id_bits;
+	}
+	info->corpus_bytes = c->total;
+	info->corpus_docs = c->D;
+	if (c->plan_valid) {
+		info->chunks = c->nchunks;
+		info->scan_path = (uint32_t)c->scan_path;
+		info->trie_lds_slots = c->tile.lds_slots;
+	}
+	return TOKSCORE_OK;
+}
+
+int tokscore_last_timing(tokscore_ctx *c, float ms[4]) {
+	if (!c || !ms) return TOKSCORE_E_ARG;
+	if (c->hostonly) return TOKSCORE_E_NO_DEVICE;
+	if (c->timing_pending) {
+		(void)hipSetDevice(c->device);
+		HIP_TRY(c, hipEventSynchronize(c->ev[4]));
+		HIP_TRY(c, hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[4]));
+		HIP_TRY(c, hipEventElapsedTime(&c->last_ms[1], c->ev[1], c->ev[2]));
+		HIP_TRY(c, hipEventElapsedTime(&c->last_ms[2], c->ev[2], c->ev[3]));
+		HIP_TRY(c, hipEventElapsedTime(&c->last_ms[3], c->ev[3], c->ev[4]));
+		c->timing_pending = false;
+	}
+	memcpy(ms, c->last_ms, sizeof c->last_ms);
+	return TOKSCORE_OK;
+}
+
+int tokscore_hosttrie_longest(tokscore_ctx *c, const uint8_t *text, uint64_t n, uint64_t *len, uint64_t *id) {
+	if (!c || !len || !id || (!text && n)) return TOKSCORE_E_ARG;
+	if (!c->vocab_set) return fail(c, TOKSCORE_E_STATE, "vocabulary not set");
+	if (!c->packed_valid) {
+		std::string e;
+		if (!c->trie.Pack(&c->packed, &e)) return fail(c, TOKSCORE_E_VOCAB, e);
+		c->packed_valid = true;
+		c->device_trie_valid = false;
+	}
+	VocabTrie::Longest(c->packed, text, n, len, id);
+	return TOKSCORE_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,275 @@
+// trie.cpp -- see trie.h.
+#include "trie.h"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace tokscore {
+
+namespace {
+inline uint8_t ascii_lower(uint8_t c) {
+	// std::tolower in the "C" locale (SolutionFile.cpp:87-88): A-Z only.
+	return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c;
+}
+inline uint32_t bit_width(uint64_t x) {
+	uint32_t b = 0;
+	while (x) {
+		b++;
+		x >>= 1;
+	}
+	return b;
+}
+} // namespace
+
+bool VocabTrie::Build(const uint8_t *bytes, const uint64_t *off, uint64_t V, std::string *err) {
+	V_ = V;
+	max_len_ = 0;
+	first_child_.clear();
+	n_children_.clear();
+	edges_.clear();
+	depth_.clear();
+	head_tok_.clear();
+	weight_.clear();
+	next_dup_.assign(V, -1);
+	tok_node_.assign(V, 0);
+	enabled_.assign(V, 1);
+	node_slot_.clear();
+	sampled_ = false;
+
+	for (uint64_t i = 0; i < V; i++) {
+		if (off[i + 1] < off[i]) {
+			if (err) *err = "vocabulary offsets are not monotone";
+			return false;
+		}
+		// max_len_ covers every entry, duplicates included (SolutionFile.cpp:55,68)
+		max_len_ = std::max<uint64_t>(max_len_, off[i + 1] - off[i]);
+	}
+	if (max_len_ == 0) {
+		if (err) *err = "vocabulary has no non-empty token (the reference would never advance)";
+		return false;
+	}
+
+	// Sort token indices by (string, index): equal strings end up adjacent in
+	// ascending index order, so the first of a run is the id the reference keeps
+	// (unordered_map::insert fails on duplicates, SolutionFile.cpp:56).
+	std::vector<uint32_t> order(V);
+	std::iota(order.begin(), order.end(), 0u);
+	auto len_of = [&](uint32_t i) { return off[i + 1] - off[i]; };
+	std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+		const uint64_t la = len_of(a), lb = len_of(b);
+		const int c = std::memcmp(bytes + off[a], bytes + off[b], (size_t)std::min(la, lb));
+		if (c != 0) return c < 0;
+		if (la != lb) return la < lb;
+		return a < b;
+	});
+
+	// Breadth-first construction over sorted ranges: the children of one node are
+	// created back to back, so every node's edges are contiguous and byte-sorted.
+	struct Range {
+		uint64_t lo, hi;
+	};
+	std::vector<Range> ranges;
+	auto new_node = [&](uint64_t lo, uint64_t hi, uint32_t depth) {
+		first_child_.push_back(0);
+		n_children_.push_back(0);
+		depth_.push_back(depth);
+		head_tok_.push_back(-1);
+		ranges.push_back({lo, hi});
+		return (uint32_t)(first_child_.size() - 1);
+	};
+	new_node(0, V, 0);
+	for (uint32_t node = 0; node < first_child_.size(); node++) {
+		uint64_t lo = ranges[node].lo;
+		const uint64_t hi = ranges[node].hi;
+		const uint32_t d = depth_[node];
+		// tokens that end exactly here (length == depth) come first in the range
+		int64_t prev = -1;
+		while (lo < hi && len_of(order[lo]) == d) {
+			const uint32_t t = order[lo];
+			tok_node_[t] = node;
+			if (d > 0) { // the empty string can never match (Tokenize tries len >= 1 only)
+				if (prev < 0) head_tok_[node] = t;
+				else next_dup_[prev] = t;
+				prev = t;
+			}
+			lo++;
+		}
+		first_child_[node] = (uint32_t)edges_.size();
+		while (lo < hi) {
+			const uint8_t c = bytes[off[order[lo]] + d];
+			uint64_t e = lo + 1;
+			while (e < hi && bytes[off[order[e]] + d] == c) e++;
+			edges_.push_back({c, 0});
+			n_children_[node]++;
+			lo = e;
+		}
+		// create the children after the edge list is complete (keeps edges contiguous)
+		lo = ranges[node].lo;
+		while (lo < hi && len_of(order[lo]) == d) lo++;
+		for (uint32_t k = 0; k < n_children_[node]; k++) {
+			const uint8_t c = edges_[first_child_[node] + k].byte;
+			uint64_t e = lo + 1;
+			while (e < hi && bytes[off[order[e]] + d] == c) e++;
+			edges_[first_child_[node] + k].child = new_node(lo, e, d + 1);
+			lo = e;
+		}
+	}
+	weight_.assign(first_child_.size(), 0);
+	root_child_.assign(256, 0);
+	for (uint32_t k = 0; k < n_children_[0]; k++) root_child_[edges_[first_child_[0] + k].byte] = edges_[first_child_[0] + k].child;
+	return true;
+}
+
+uint32_t VocabTrie::Child(uint32_t node, uint8_t c) const {
+	if (node == 0) return root_child_[c];
+	const Edge *e = edges_.data() + first_child_[node];
+	uint32_t lo = 0, hi = n_children_[node];
+	while (lo < hi) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (e[mid].byte < c) lo = mid + 1;
+		else hi = mid;
+	}
+	return (lo < n_children_[node] && e[lo].byte == c) ? e[lo].child : 0;
+}
+
+uint32_t VocabTrie::ActiveId(uint32_t node) const {
+	for (int64_t t = head_tok_[node]; t >= 0; t = next_dup_[t])
+		if (enabled_[t]) return (uint32_t)t + 2; // token i -> id i+2 (SolutionFile.cpp:49-57)
+	return 0;
+}
+
+void VocabTrie::AddHotnessSample(const uint8_t *sample, uint64_t n) {
+	uint64_t pos = 0;
+	while (pos < n) {
+		uint32_t node = 0;
+		uint64_t len = 0;
+		for (uint64_t d = 0; pos + d < n; d++) {
+			if (n_children_[node] == 0) break;
+			weight_[node]++;
+			const uint32_t ch = Child(node, ascii_lower(sample[pos + d]));
+			if (!ch) break;
+			node = ch;
+			if (ActiveId(node)) len = d + 1;
+		}
+		pos += len ? len : 1;
+	}
+	sampled_ = true;
+}
+
+bool VocabTrie::Pack(PackedTrie *out, std::string *err) {
+	const uint32_t N = (uint32_t)first_child_.size();
+	// Parents ordered hot-first; unsampled tries fall back to breadth-first order
+	// (node numbering is already breadth-first), i.e. "top levels first".
+	std::vector<uint32_t> parents;
+	parents.reserve(N);
+	for (uint32_t n = 1; n < N; n++)
+		if (n_children_[n]) parents.push_back(n);
+	if (sampled_) {
+		std::stable_sort(parents.begin(), parents.end(), [&](uint32_t a, uint32_t b) { return weight_[a] > weight_[b]; });
+	}
+	parents.insert(parents.begin(), 0u); // the root always goes first
+
+	std::vector<uint8_t> used(1024, 0);
+	auto ensure = [&](uint64_t n) {
+		if (used.size() < n) used.resize(std::max<uint64_t>(n, used.size() * 2), 0);
+	};
+	node_slot_.assign(N, 0);
+	std::vector<uint32_t> node_base(N, 0);
+	used[0] = 1; // root
+	uint64_t first_free = 1;
+	uint64_t max_used = 0;
+	for (uint32_t node : parents) {
+		const Edge *e = edges_.data() + first_child_[node];
+		const uint32_t nc = n_children_[node];
+		const uint32_t c0 = e[0].byte;
+		while (first_free < used.size() && used[first_free]) first_free++;
+		// smallest base b >= 1 with every slot b + c free
+		uint64_t b = first_free > c0 ? first_free - c0 : 1;
+		for (;;) {
+			ensure(b + 257);
+			bool ok = true;
+			for (uint32_t k = 0; k < nc; k++) {
+				if (used[b + e[k].byte]) {
+					ok = false;
+					break;
+				}
+			}
+			if (ok) break;
+			b++;
+			// skip ahead to the next base whose first child slot is free
+			while (b + c0 < used.size() && used[b + c0]) b++;
+		}
+		node_base[node] = (uint32_t)b;
+		for (uint32_t k = 0; k < nc; k++) {
+			used[b + e[k].byte] = 1;
+			node_slot_[e[k].child] = (uint32_t)(b + e[k].byte);
+			max_used = std::max<uint64_t>(max_used, b + e[k].byte);
+		}
+	}
+	const uint64_t nslots = max_used + 1 + 256; // base + 255 is always a readable slot
+	const uint32_t sb = bit_width(nslots);      // (1<<sb)-1 >= nslots: never a valid slot
+	const uint32_t ib = std::max<uint32_t>(1, bit_width(V_ + 1));
+	if (2 * sb + ib > 64 || sb > 31) {
+		if (err) *err = "vocabulary too large for the packed trie entry (2*slot_bits + id_bits > 64)";
+		return false;
+	}
+	out->slot_bits = sb;
+	out->id_bits = ib;
+	out->nodes = N;
+	out->max_len = max_len_;
+	out->unknown_id = (uint32_t)(V_ + 2);
+	const uint64_t pm = (1ull << sb) - 1;
+	out->slots.assign(nslots, pm); // empty: parent = all ones, base = 0, id = 0
+	for (uint32_t node = 0; node < N; node++) {
+		const uint32_t slot = node_slot_[node];
+		uint64_t entry = (node == 0) ? pm : 0; // parent filled in below for non-root nodes
+		entry |= (uint64_t)node_base[node] << sb;
+		entry |= (uint64_t)ActiveId(node) << (2 * sb);
+		out->slots[slot] = entry; // slot 0 for the root; unique per node otherwise
+	}
+	// parent fields: walk the edges
+	for (uint32_t node = 0; node < N; node++) {
+		const Edge *e = edges_.data() + first_child_[node];
+		for (uint32_t k = 0; k < n_children_[node]; k++) {
+			const uint32_t cs = node_slot_[e[k].child];
+			out->slots[cs] = (out->slots[cs] & ~pm) | node_slot_[node];
+		}
+	}
+	return true;
+}
+
+int64_t VocabTrie::Toggle(uint64_t token, bool enable, PackedTrie *packed, uint64_t *new_entry) {
+	if (token >= V_) return -1;
+	enabled_[token] = enable ? 1 : 0;
+	const uint32_t node = tok_node_[token];
+	if (node == 0 || node_slot_.empty()) return -1; // empty string, or not packed yet
+	const uint32_t slot = node_slot_[node];
+	const uint32_t sb = packed->slot_bits;
+	const uint64_t keep = (sb == 32) ? ~0ull : ((1ull << (2 * sb)) - 1);
+	const uint64_t e = (packed->slots[slot] & keep) | ((uint64_t)ActiveId(node) << (2 * sb));
+	if (e == packed->slots[slot]) return -1;
+	packed->slots[slot] = e;
+	*new_entry = e;
+	return slot;
+}
+
+void VocabTrie::Longest(const PackedTrie &p, const uint8_t *text, uint64_t n, uint64_t *len, uint64_t *id) {
+	*len = 0;
+	*id = 0;
+	uint32_t node = 0;
+	uint32_t base = p.base(p.slots[0]);
+	for (uint64_t d = 0; d < n && base; d++) {
+		const uint32_t t = base + ascii_lower(text[d]);
+		const uint64_t e = p.slots[t];
+		if (p.parent(e) != node) break;
+		node = t;
+		base = p.base(e);
+		if (p.id(e)) {
+			*len = d + 1;
+			*id = p.id(e);
+		}
+	}
+}
+
+} // namespace tokscore
