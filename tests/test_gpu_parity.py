@@ -100,6 +100,16 @@ def test_wide_vocabulary_uses_32bit_stream():
     # V + 3 > 32767 forces 32-bit stream entries and two histogram id ranges
     corpus, off = synth.random_utf8(1_000_000, seed=11, doc_lo=512, doc_hi=100_000)
     tokens = synth.build_vocab(corpus, 40000)
+    # random text has too few repeated n-grams: top the list up with slices of the corpus
+    text = corpus.tobytes().decode("utf-8")
+    seen = set(tokens)
+    k = 0
+    while len(tokens) < 36000:
+        t = text[k * 7:k * 7 + 2 + k % 4].encode("utf-8")
+        k += 1
+        if t and t not in seen:
+            seen.add(t)
+            tokens.append(t)
     assert len(tokens) > 33000
     voc = O.OracleVocab(*synth.pack_vocab(tokens))
     exp = voc.score(corpus, off, threads=8)

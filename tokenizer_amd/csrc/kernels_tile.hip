@@ -21,6 +21,9 @@
 // a full-vocabulary LDS histogram per workgroup.  Results equal the serial loop exactly.
 #include "kernels.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace tokscore {
 
 namespace {
