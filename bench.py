@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: corpus GB/s scored per full-vocabulary evaluation.
+
+A step is ONE full-vocabulary scoring pass (greedy longest-match segmentation of every
+document + per-id counts + totals; /root/reference/src/main.cpp:31-46 over
+SolutionFile::Tokenize) of the rank's resident shard, followed for N > 1 by one RCCL
+all-reduce of counts | total_tokens | total_bytes.  Workload = BASELINE.json configs[1]:
+a ~100 MB wiki-like shard (seeded synthetic stand-in) with a 32k
+vocabulary per GPU; every rank scores its own shard (weak scaling, no data-path collective
+besides the count all-reduce).
+
+    python bench.py [--gpus N --steps K --warmup W] [--mb 100] [--vocab 32000]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints one JSON line on rank 0.  The CPU oracle / compiled reference is timed beside it
+(cpu_baseline) on a bounded sample; it is never part of the measured GPU path.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def cpu_baseline(corpus, off, tokens, sample_bytes=32_000_000):
+    """Reference CPU path on the host cores, on the first ~sample_bytes of the shard."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tokenizer_amd import synth
+    d_end = int(np.searchsorted(off, sample_bytes, side="right")) - 1
+    d_end = max(1, min(d_end, len(off) - 1))
+    sub_off = off[:d_end + 1]
+    nbytes = int(sub_off[-1])
+    cores = min(16, os.cpu_count() or 1)  # the GPU box grants 16 host cores per GPU
+    out = {}
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    if os.path.exists(harness):
+        with tempfile.TemporaryDirectory() as tmp:
+            b = corpus[:nbytes].tobytes()
+            texts = [b[int(sub_off[i]):int(sub_off[i + 1])].decode("utf-8") for i in range(d_end)]
+            with open(os.path.join(tmp, "t.json"), "w", encoding="utf-8") as f:
+                json.dump({"version": "0.4.0", "tokens": [t.decode("utf-8") for t in tokens]}, f, ensure_ascii=False)
+            with open(os.path.join(tmp, "s.json"), "w", encoding="utf-8") as f:
+                json.dump([{"id": str(i), "title": "", "text": x} for i, x in enumerate(texts)], f, ensure_ascii=False)
+            subprocess.run([harness, "score", os.path.join(tmp, "t.json"), os.path.join(tmp, "s.json"),
+                            os.path.join(tmp, "e.json"), "--threads", str(cores)], check=True,
+                           stdout=subprocess.DEVNULL)
+            e = json.load(open(os.path.join(tmp, "e.json")))
+        out = {"value": nbytes / e["tokenize_seconds"] / 1e9, "unit": "GB/s", "cores": cores, "kind": "reference",
+               "sample": "first %d documents (%d bytes) of the rank-0 shard, compiled reference "
+                         "SolutionFile::Tokenize on %d threads, Tokenize time only" % (d_end, nbytes, cores)}
+    import oracle_ffi as O
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    t0 = time.time()
+    voc.score(corpus[:nbytes], sub_off, threads=cores)
+    port = nbytes / (time.time() - t0) / 1e9
+    if not out:
+        out = {"value": port, "unit": "GB/s", "cores": cores, "kind": "port",
+               "sample": "first %d documents (%d bytes) of the rank-0 shard, oracle/tokscore_oracle.c on %d threads"
+                         % (d_end, nbytes, cores)}
+    out["port_value"] = port
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mb", type=float, default=100.0, help="shard size per GPU in MB")
+    ap.add_argument("--vocab", type=int, default=32000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import tokenizer_amd as ta
+    from tokenizer_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic shard (configs[1] stand-in) and a vocabulary shared by all ranks ----
+    nbytes = int(args.mb * 1e6)
+    vocab_src, _ = synth.wiki_like(2_000_000, seed=20201120)
+    tokens = synth.build_vocab(vocab_src, args.vocab)
+    corpus, off = synth.wiki_like(nbytes, seed=20201120 + rank)
+    V = len(tokens)
+
+    scorer = ta.Scorer(local_rank)  # raises when the HIP library or the GPU is missing
+    scorer.set_vocab(*synth.pack_vocab(tokens))
+    t0 = time.time()
+    scorer.set_corpus(corpus, off)
+    h2d_s = time.time() - t0
+
+    out = torch.zeros(V + 5, dtype=torch.int64, device=dev)  # counts | total_tokens | total_bytes
+    stream = torch.cuda.current_stream()
+
+    def step():
+        scorer.score_async(out.data_ptr(), stream.cuda_stream)
+        if world > 1:
+            dist.all_reduce(out)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    scorer.drain_timings()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    # HIP events the library recorded around its kernels, on the stream they ran on,
+    # for exactly the K timed steps (read after the region: no host sync inside it)
+    tm = scorer.drain_timings()[-args.steps:]
+    eval_ms = [t[0] for t in tm]
+    scan_ms = [t[1] for t in tm]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    host = out.cpu().numpy().view(np.uint64)
+    total_bytes_all = int(host[V + 4])  # after the all-reduce: all ranks' bytes
+    info = scorer.info()
+    if rank == 0:
+        value = total_bytes_all * args.steps / elapsed / 1e9
+        alg_bytes = int(info.corpus_bytes) + 8 * (V + 3)
+        scan_avg_ms = float(np.mean(scan_ms))
+        achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
+        rec = {
+            "metric": "corpus GB/s scored per full-vocab eval",
+            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "configs[1]: wiki-like %.0f MB shard per GPU (seed 20201120+rank), "
+                                   "one full-vocabulary scoring pass, V=%d" % (args.mb, V),
+                       "docs_per_gpu": int(info.corpus_docs), "bytes_per_gpu": int(info.corpus_bytes),
+                       "vocab": V, "max_token_bytes": int(info.max_len), "trie_slots": int(info.trie_slots),
+                       "trie_lds_slots": int(info.trie_lds_slots), "chunks": int(info.chunks),
+                       "scan_path": "lds_tile" if info.scan_path == 1 else "generic",
+                       "parallelism": "documents sharded over %d GPU(s), 1 count all-reduce" % world},
+            "roofline": {"bound": "hbm", "kernel": "scan_tile_kernel" if info.scan_path == 1 else "scan_generic_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None, "alg_bytes_per_launch": alg_bytes, "kernel_ms": scan_avg_ms,
+                         "eval_kernels_ms": float(np.mean(eval_ms))},
+            "total_tokens": int(host[V + 3]), "h2d_inclusive_GBps": info.corpus_bytes / (h2d_s + elapsed / args.steps) / 1e9,
+        }
+        if world == 1 and not args.no_cpu:
+            rec["cpu_baseline"] = cpu_baseline(corpus, off, tokens)
+        print(json.dumps(rec))
+    scorer.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -137,6 +137,12 @@ int tokscore_get_info(tokscore_ctx *ctx, tokscore_info *info);
  * [2] boundary fix-up kernels, [3] histogram + reduce kernels. */
 int tokscore_last_timing(tokscore_ctx *ctx, float ms[4]);
 
+/* Same four durations for every score call since the previous drain (oldest first, at most
+ * the last 256 calls), so a benchmark can enqueue many evaluations back to back and read the
+ * kernel times afterwards without a host sync inside its timed region.  ms holds 4*cap
+ * floats; *n receives the number of calls reported. */
+int tokscore_drain_timings(tokscore_ctx *ctx, float *ms, uint32_t cap, uint32_t *n);
+
 /* Host-side self-check of the packed double-array trie (no GPU involved, used by the
  * CPU test-suite to validate the builder): longest enabled vocabulary entry that is a
  * prefix of text[0..n).  *len = 0 when none.  Never used by any scoring entry point. */

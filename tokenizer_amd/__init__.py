@@ -51,6 +51,7 @@ _SIGNATURES = [
     ("tokscore_tokenize", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, C.c_uint64, _u64p]),
     ("tokscore_get_info", C.c_int, [C.c_void_p, C.POINTER(TokscoreInfo)]),
     ("tokscore_last_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    ("tokscore_drain_timings", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     ("tokscore_hosttrie_longest", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u64p]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -182,6 +183,13 @@ class Scorer:
         ms = (C.c_float * 4)()
         self._check(self._lib.tokscore_last_timing(self._h, ms))
         return [float(x) for x in ms]
+
+    def drain_timings(self, cap: int = 256):
+        """[(eval, scan, fixup, hist+reduce) ms] for every score call since the last drain."""
+        ms = (C.c_float * (4 * cap))()
+        n = C.c_uint32()
+        self._check(self._lib.tokscore_drain_timings(self._h, ms, cap, C.byref(n)))
+        return [[float(ms[4 * i + k]) for k in range(4)] for i in range(int(n.value))]
 
     def hosttrie_longest(self, text: bytes):
         a = np.frombuffer(text, dtype=np.uint8) if text else np.zeros(1, dtype=np.uint8)

@@ -36,7 +36,13 @@ struct tokscore_ctx {
 	int device = -1;
 	int num_cus = 256;
 	hipStream_t stream = nullptr;
-	hipEvent_t ev[5] = {};
+	// ring of event sets, one per score call, so a caller can time many calls back to back and
+	// read the kernel durations afterwards without a host sync inside its timed region
+	static constexpr int kRing = 256;
+	hipEvent_t ring[kRing][5] = {};
+	hipEvent_t *ev = ring[0];
+	uint64_t calls = 0;   // score calls enqueued
+	uint64_t drained = 0; // calls whose timings were handed out by tokscore_drain_timings
 	std::string err;
 
 	// vocabulary
@@ -260,6 +266,8 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
 	ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
 	             c->d_chunk_state + 2 * (size_t)(c->nchunks + 1), c->nchunks};
+	c->ev = c->ring[c->calls % tokscore_ctx::kRing];
+	c->calls++;
 	HIP_TRY(c, hipEventRecord(c->ev[0], s));
 	HIP_TRY(c, hipMemsetAsync(d_out, 0, (c->V + 5) * sizeof(unsigned long long), s));
 	if (c->scan_path == 1) {
@@ -335,10 +343,12 @@ int tokscore_create(tokscore_ctx **out, int device) {
 		delete c;
 		return TOKSCORE_E_HIP;
 	}
-	for (auto &e : c->ev) {
-		if (hipEventCreate(&e) != hipSuccess) {
-			delete c;
-			return TOKSCORE_E_HIP;
+	for (auto &set : c->ring) {
+		for (auto &e : set) {
+			if (hipEventCreate(&e) != hipSuccess) {
+				delete c;
+				return TOKSCORE_E_HIP;
+			}
 		}
 	}
 	*out = c;
@@ -362,8 +372,9 @@ void tokscore_destroy(tokscore_ctx *c) {
 		free_corpus(c);
 		if (c->d_slots) (void)hipFree(c->d_slots);
 		if (c->d_out) (void)hipFree(c->d_out);
-		for (auto &e : c->ev)
-			if (e) (void)hipEventDestroy(e);
+		for (auto &set : c->ring)
+			for (auto &e : set)
+				if (e) (void)hipEventDestroy(e);
 		if (c->stream) (void)hipStreamDestroy(c->stream);
 	}
 	delete c;
@@ -587,6 +598,26 @@ int tokscore_last_timing(tokscore_ctx *c, float ms[4]) {
 		c->timing_pending = false;
 	}
 	memcpy(ms, c->last_ms, sizeof c->last_ms);
+	return TOKSCORE_OK;
+}
+
+int tokscore_drain_timings(tokscore_ctx *c, float *ms, uint32_t cap, uint32_t *n) {
+	if (!c || !ms || !n) return TOKSCORE_E_ARG;
+	if (c->hostonly) return TOKSCORE_E_NO_DEVICE;
+	(void)hipSetDevice(c->device);
+	uint64_t first = c->drained;
+	if (c->calls - first > (uint64_t)tokscore_ctx::kRing) first = c->calls - tokscore_ctx::kRing;
+	uint32_t k = 0;
+	for (uint64_t i = first; i < c->calls && k < cap; i++, k++) {
+		hipEvent_t *e = c->ring[i % tokscore_ctx::kRing];
+		HIP_TRY(c, hipEventSynchronize(e[4]));
+		HIP_TRY(c, hipEventElapsedTime(&ms[4 * k + 0], e[0], e[4]));
+		HIP_TRY(c, hipEventElapsedTime(&ms[4 * k + 1], e[1], e[2]));
+		HIP_TRY(c, hipEventElapsedTime(&ms[4 * k + 2], e[2], e[3]));
+		HIP_TRY(c, hipEventElapsedTime(&ms[4 * k + 3], e[3], e[4]));
+	}
+	c->drained = first + k;
+	*n = k;
 	return TOKSCORE_OK;
 }
 
