@@ -36,7 +36,7 @@ enum {
 	TOKSCORE_E_STATE = 4,      /* vocabulary or corpus not set yet */
 	TOKSCORE_E_VOCAB = 5,      /* vocabulary unusable: no non-empty token (the reference
 	                              would loop forever, SolutionFile.cpp:89-97), or too large
-	                              for the packed trie entry (2*slot_bits + id_bits > 64) */
+	                              for the packed trie (more than 2^23 double-array slots) */
 	TOKSCORE_E_CAPACITY = 6,   /* output buffer too small / internal stream overflow */
 	TOKSCORE_E_INTERNAL = 7
 };
@@ -71,8 +71,8 @@ int tokscore_set_vocab(tokscore_ctx *ctx, const uint8_t *bytes, const uint64_t *
 int tokscore_vocab_max_len(const tokscore_ctx *ctx, uint64_t *max_len);
 
 /* Annealing move on the scored vocabulary: disable / re-enable entry `token_index`
- * without rebuilding the trie (a disabled entry can never be emitted; duplicates of
- * its string are not promoted).  There is no reference counterpart on the corpus
+ * without rebuilding the trie.  A disabled entry can never be emitted; if a later entry
+ * holds the same string it takes over, exactly as in the vocabulary without the entry.  There is no reference counterpart on the corpus
  * path: the reference judges moves on the candidate DAG (src/tokenizer/Token.cpp:83-105);
  * parity is defined as "equal to a full score with the toggled vocabulary". */
 int tokscore_toggle(tokscore_ctx *ctx, uint64_t token_index, int enable);
@@ -125,7 +125,7 @@ typedef struct {
 	uint64_t corpus_bytes;
 	uint64_t corpus_docs;
 	uint64_t chunks;          /* wave work units of the scan kernel */
-	uint32_t slot_bits;       /* packed entry = parent:slot_bits | base:slot_bits | id:id_bits */
+	uint32_t slot_bits;       /* packed slot = label:8 | valid:1 | base:slot_bits, then id:id_bits */
 	uint32_t id_bits;
 	uint32_t scan_path;       /* 1 = LDS tile scan kernel, 0 = generic global-memory scan */
 	uint32_t reserved;

@@ -12,14 +12,17 @@
 
 namespace tokscore {
 
+// Packed trie slot (see trie.h): w0 = label:8 | valid:1 | base:23, w1 = id.
+constexpr uint32_t kSlotValid = 0x100u;
+constexpr uint32_t kSlotKeyMask = 0x1FFu;
+constexpr uint32_t kSlotBaseShift = 9;
+
 struct TrieDev {
-	const uint64_t *slots; // packed double array in HBM (L2-resident in practice)
+	const uint2 *slots;  // packed double array in HBM (L2-resident in practice)
 	uint32_t nslots;
-	uint32_t slot_bits;
-	uint32_t pmask;      // (1 << slot_bits) - 1
-	uint32_t id_shift;   // 2 * slot_bits
 	uint32_t unknown_id; // V + 2
 	uint32_t lds_slots;  // slots [0, lds_slots) are staged in LDS by the tile scan
+	uint32_t root_base;  // base of slot 0
 };
 
 struct CorpusDev {
@@ -59,23 +62,19 @@ __device__ __forceinline__ uint64_t next_boundary(const CorpusDev &C, uint64_t p
 // One token of the greedy chain, trie and corpus both read from global memory.
 __device__ __forceinline__ void walk_token_global(const TrieDev &T, const uint8_t *bytes, uint64_t pos,
                                                   uint64_t limit, uint32_t &len, uint32_t &id) {
-	uint32_t node = 0;
-	uint32_t base = (uint32_t)(T.slots[0] >> T.slot_bits) & T.pmask;
+	uint32_t base = T.root_base;
 	uint32_t d = 0;
 	len = 0;
 	id = T.unknown_id;
 	while (base != 0 && pos + d < limit) {
 		const uint32_t c = lower8(bytes[pos + d]);
-		const uint32_t t = base + c;
-		const uint64_t e = T.slots[t];
-		if (((uint32_t)e & T.pmask) != node) break;
-		node = t;
+		const uint2 e = T.slots[base + c];
+		if ((e.x & kSlotKeyMask) != (c | kSlotValid)) break;
 		d++;
-		base = (uint32_t)(e >> T.slot_bits) & T.pmask;
-		const uint32_t tid = (uint32_t)(e >> T.id_shift);
-		if (tid) {
+		base = e.x >> kSlotBaseShift;
+		if (e.y) {
 			len = d;
-			id = tid;
+			id = e.y;
 		}
 	}
 	if (len == 0) len = 1; // UNKNOWN advances one byte (SolutionFile.cpp:92-94)

@@ -24,10 +24,11 @@ struct TileScanPlan {
 	uint32_t wide_ids;        // 0: 16-bit stream entries, 1: 32-bit
 };
 struct StreamDev {
-	void *blocks;              // token stream, 1 KiB blocks
+	void *blocks;              // token stream, blocks of stream_block_bytes()
 	uint32_t capacity_blocks;
 	uint32_t *cursor;          // [0] blocks handed out, [1] overflow flag, [2] next work chunk
 };
+uint32_t stream_block_bytes(uint32_t wide_ids);
 bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num_cus, TileScanPlan *plan);
 void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S, const StreamDev &Q,
                       const TileScanPlan &plan, const uint64_t *chunk_first_doc, uint64_t max_len,

@@ -11,14 +11,15 @@
 //   bounds   document starts inside the tile become a bitmap; a match window is clipped
 //            at the next start (`input.size() - pos`, SolutionFile.cpp:90);
 //   phase 1  every lane walks the greedy chain of its own segment from the segment's
-//            first byte -- one trie step per iteration in one flat loop, so lanes never
-//            wait for each other's token ends -- and appends the ids it emits to the
-//            wave's queue (ballot + prefix count, no atomics);
+//            first byte -- one trie lookup per iteration in one flat loop, so lanes never
+//            wait for each other's token ends -- and logs the ids it emits in its own
+//            column of the wave's LDS log block (no cross-lane traffic);
 //   phase 2  lane k's true entry is lane k-1's exit overshoot.  Lanes whose guess (0) was
 //            wrong dual-walk the true chain (+ entries) against the guessed one (- entries)
 //            until the chains meet; exits that change are settled in lane order.
-// The queue drains to HBM in 1 KiB blocks; hist_kernel turns the stream into counts with
-// a full-vocabulary LDS histogram per workgroup.  Results equal the serial loop exactly.
+// A log block goes to HBM whenever one lane's column is full (unused cells are null
+// entries); hist_kernel turns the stream into counts with an LDS histogram per workgroup.
+// Results equal the serial loop exactly.
 #include "kernels.h"
 
 #include <algorithm>
@@ -28,9 +29,12 @@ namespace tokscore {
 
 namespace {
 
-constexpr uint32_t kQueueFlush16 = 512; // entries per 1 KiB block, 16-bit ids
-constexpr uint32_t kQueueFlush32 = 256; // entries per 1 KiB block, 32-bit ids
+#define LDS_AS __attribute__((address_space(3)))
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr uint32_t kNoLimit = 0x7FFFFFFFu;
+constexpr uint32_t kLogDepth = 8; // stream entries per lane per log block
 
 __device__ __forceinline__ void wave_sync() {
 	// LDS is in order per wave; this only stops the compiler moving LDS accesses across.
@@ -50,27 +54,19 @@ __device__ __forceinline__ uint32_t lower4(uint32_t x) {
 template <bool WIDE> struct QTraits;
 template <> struct QTraits<false> {
 	using entry_t = uint16_t;
-	static constexpr uint32_t flush = kQueueFlush16;
 	static constexpr uint32_t neg = 0x8000u;
 	static constexpr uint32_t null_entry = 0x7FFFu;
+	static constexpr uint32_t null_word = 0x7FFF7FFFu;
 };
 template <> struct QTraits<true> {
 	using entry_t = uint32_t;
-	static constexpr uint32_t flush = kQueueFlush32;
 	static constexpr uint32_t neg = 0x80000000u;
 	static constexpr uint32_t null_entry = 0x7FFFFFFFu;
-};
-
-struct WaveCtx {
-	const uint64_t *lds_trie;
-	const uint8_t *tile;   // LDS, tile-relative byte offsets
-	const uint32_t *bitmap; // LDS, bit i = a document starts at tile byte i
-	uint32_t lds_slots;
-	uint32_t root_base;
+	static constexpr uint32_t null_word = 0x7FFFFFFFu;
 };
 
 // next document start strictly after pos, looked up to `stop` (exclusive)
-__device__ __forceinline__ uint32_t find_limit(const uint32_t *bm, uint32_t pos, uint32_t stop) {
+__device__ __forceinline__ uint32_t find_limit(const LDS_AS uint32_t *bm, uint32_t pos, uint32_t stop) {
 	const uint32_t i = pos + 1;
 	uint32_t w = i >> 5;
 	uint32_t word = bm[w] >> (i & 31);
@@ -82,57 +78,64 @@ __device__ __forceinline__ uint32_t find_limit(const uint32_t *bm, uint32_t pos,
 	return kNoLimit;
 }
 
-template <bool WIDE> struct Queue {
+// The wave's log block in LDS: cell (k, lane) at [k * 64 + lane]; lane `lane` owns column
+// `lane` and fills it top down.  Written to the stream as it stands (order is irrelevant to
+// a histogram), null cells included.
+template <bool WIDE> struct LaneLog {
 	using Q = QTraits<WIDE>;
-	typename Q::entry_t *buf; // LDS, wave private
-	uint32_t count;           // wave uniform
+	LDS_AS typename Q::entry_t *cells;
+	uint32_t k; // per lane: cells used in this lane's column
 
-	__device__ __forceinline__ void flush_block(const StreamDev &S, uint32_t lane) {
+	__device__ __forceinline__ void clear(uint32_t lane) {
+		constexpr uint32_t words = 64 * kLogDepth * sizeof(typename Q::entry_t) / 4;
+		LDS_AS uint32_t *w = (LDS_AS uint32_t *)cells;
+		for (uint32_t i = lane; i < words; i += 64) w[i] = Q::null_word;
+		k = 0;
+	}
+	__device__ __forceinline__ void put(uint32_t lane, uint32_t val) {
+		cells[k * 64 + lane] = (typename Q::entry_t)val;
+		k++;
+	}
+	// wave-uniform call: send the block out and start an empty one
+	__device__ __forceinline__ void flush(const StreamDev &S, uint32_t lane) {
+		constexpr uint32_t vecs = 64 * kLogDepth * sizeof(typename Q::entry_t) / 16; // 16-byte vectors
 		uint32_t blk = 0;
 		if (lane == 0) blk = atomicAdd(&S.cursor[0], 1u);
 		blk = __builtin_amdgcn_readfirstlane(blk);
 		wave_sync();
 		if (blk < S.capacity_blocks) {
-			const uint4 v = reinterpret_cast<const uint4 *>(buf)[lane];
-			reinterpret_cast<uint4 *>(S.blocks)[(size_t)blk * 64 + lane] = v;
+			const LDS_AS u32x4 *src = (const LDS_AS u32x4 *)cells;
+			u32x4 *dst = reinterpret_cast<u32x4 *>(S.blocks) + (size_t)blk * vecs;
+			for (uint32_t i = lane; i < vecs; i += 64) dst[i] = src[i];
 		} else if (lane == 0) {
 			S.cursor[1] = 1u; // overflow: reported by the host, never silently dropped
 		}
 		wave_sync();
+		clear(lane);
+		wave_sync();
 	}
-
-	// append `val` from every lane with pred set
-	__device__ __forceinline__ void push(bool pred, uint32_t val, const StreamDev &S, uint32_t lane) {
-		const unsigned long long m = __ballot(pred);
-		if (m == 0) return;
-		const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0));
-		if (pred) buf[count + rank] = (typename Q::entry_t)val;
-		count += (uint32_t)__builtin_popcountll(m);
-		if (count >= Q::flush) {
-			flush_block(S, lane);
-			const uint32_t rem = count - Q::flush; // < 64
-			typename Q::entry_t keep = 0;
-			if (lane < rem) keep = buf[Q::flush + lane];
-			wave_sync();
-			if (lane < rem) buf[lane] = keep;
-			wave_sync();
-			count = rem;
-		}
+	__device__ __forceinline__ void flush_if_full(const StreamDev &S, uint32_t lane) {
+		if (__ballot(k >= kLogDepth)) flush(S, lane);
 	}
-
 	__device__ __forceinline__ void finish(const StreamDev &S, uint32_t lane) {
-		if (count == 0) return;
-		for (uint32_t i = count + lane; i < Q::flush; i += 64) buf[i] = (typename Q::entry_t)Q::null_entry;
-		flush_block(S, lane);
-		count = 0;
+		if (__ballot(k != 0)) flush(S, lane);
 	}
 };
 
-// One greedy chain walker state (per lane).
+struct WaveCtx {
+	const LDS_AS u32x2 *lds_trie;
+	const u32x2 *g_trie;
+	const LDS_AS uint8_t *tile;    // tile-relative byte offsets
+	const LDS_AS uint32_t *bitmap; // bit i = a document starts at tile byte i
+	uint32_t lds_slots;
+	uint32_t root_base;
+	uint32_t unknown_id;
+};
+
+// One greedy chain walker (per lane): the token in progress started at `pos`.
 struct Walker {
-	uint32_t node, base, d, last_len, last_id;
+	uint32_t base, d, last_len, last_id;
 	__device__ __forceinline__ void reset(uint32_t root_base) {
-		node = 0;
 		base = root_base;
 		d = 0;
 		last_len = 0;
@@ -140,32 +143,32 @@ struct Walker {
 	}
 };
 
-// One trie step at tile byte q (or end of token).  Returns true when the token that
-// started at `pos` is complete; then len/id hold it.
-__device__ __forceinline__ bool walk_step(const WaveCtx &W, const TrieDev &T, Walker &w, uint32_t pos, uint32_t limit,
-                                          uint32_t &len, uint32_t &id) {
+// One trie lookup for the token that started at pos.  Returns true when the token is
+// complete (miss, window clipped, or a leaf was reached); then len/id hold it.
+__device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t pos, uint32_t limit, uint32_t &len,
+                                          uint32_t &id) {
 	const uint32_t q = pos + w.d;
-	bool hit = false;
-	if (w.base != 0 && q < limit) {
+	bool more = false;
+	if (q < limit) {
 		const uint32_t c = W.tile[q];
 		const uint32_t t = w.base + c;
-		const uint64_t e = (t < W.lds_slots) ? W.lds_trie[t] : T.slots[t];
-		if (((uint32_t)e & T.pmask) == w.node) {
-			hit = true;
-			w.node = t;
+		u32x2 e;
+		if (t < W.lds_slots) e = W.lds_trie[t];
+		else e = W.g_trie[t];
+		if ((e.x & kSlotKeyMask) == (c | kSlotValid)) {
 			w.d++;
-			w.base = (uint32_t)(e >> T.slot_bits) & T.pmask;
-			const uint32_t tid = (uint32_t)(e >> T.id_shift);
-			if (tid) {
+			w.base = e.x >> kSlotBaseShift;
+			if (e.y) {
 				w.last_len = w.d;
-				w.last_id = tid;
+				w.last_id = e.y;
 			}
+			more = w.base != 0; // a leaf ends the token without another lookup
 		}
 	}
-	if (hit) return false;
+	if (more) return false;
 	// SolutionFile.cpp:92-94: nothing matched down to len 1 -> UNKNOWN, advance one byte
 	len = w.last_len ? w.last_len : 1u;
-	id = w.last_len ? w.last_id : T.unknown_id;
+	id = w.last_len ? w.last_id : W.unknown_id;
 	return true;
 }
 
@@ -177,30 +180,36 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	using Q = QTraits<WIDE>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)smem;
 
 	// ---- stage the hot trie slots in LDS (shared by the workgroup's waves) ----
-	uint64_t *lds_trie = reinterpret_cast<uint64_t *>(smem);
-	for (uint32_t i = threadIdx.x; i < T.lds_slots; i += blockDim.x) lds_trie[i] = T.slots[i];
+	{
+		LDS_AS u32x2 *dst = (LDS_AS u32x2 *)lds;
+		const u32x2 *src = reinterpret_cast<const u32x2 *>(T.slots);
+		for (uint32_t i = threadIdx.x; i < T.lds_slots; i += blockDim.x) dst[i] = src[i];
+	}
 	__syncthreads();
 
-	const uint32_t tile_span = 64 * seg_bytes;                 // bytes owned by one tile
-	const uint32_t tile_cap = tile_span + halo_bytes + 16;      // bytes staged (halo + alignment slack)
-	const uint32_t n_vec = (tile_cap + 15) / 16;                // 16-byte vectors per tile
+	const uint32_t tile_span = 64 * seg_bytes;            // bytes owned by one tile
+	const uint32_t tile_cap = tile_span + halo_bytes + 16; // bytes staged (halo + alignment slack)
+	const uint32_t n_vec = (tile_cap + 15) / 16;           // 16-byte vectors per tile
 	const uint32_t bm_words = (tile_cap + 31) / 32 + 1;
-	unsigned char *wbase = smem + (size_t)T.lds_slots * 8 + (size_t)wave * wave_lds_bytes;
-	unsigned char *tile = wbase;
-	uint32_t *bitmap = reinterpret_cast<uint32_t *>(wbase + n_vec * 16);
-	Queue<WIDE> queue;
-	queue.buf = reinterpret_cast<typename Q::entry_t *>(wbase + n_vec * 16 + ((bm_words * 4 + 15) & ~15u));
-	queue.count = 0;
+	LDS_AS unsigned char *wbase = lds + T.lds_slots * 8 + wave * wave_lds_bytes;
+	LDS_AS unsigned char *tile = wbase;
+	LDS_AS uint32_t *bitmap = (LDS_AS uint32_t *)(wbase + n_vec * 16);
+	LaneLog<WIDE> log;
+	log.cells = (LDS_AS typename Q::entry_t *)(wbase + n_vec * 16 + ((bm_words * 4 + 15) & ~15u));
+	log.clear(lane);
 
 	WaveCtx W;
-	W.lds_trie = lds_trie;
+	W.lds_trie = (const LDS_AS u32x2 *)lds;
+	W.g_trie = reinterpret_cast<const u32x2 *>(T.slots);
 	W.tile = tile;
 	W.bitmap = bitmap;
 	W.lds_slots = T.lds_slots;
-	W.root_base = (uint32_t)(lds_trie[0] >> T.slot_bits) & T.pmask;
+	W.root_base = T.root_base;
+	W.unknown_id = T.unknown_id;
 
 	constexpr int kMaxVec = 5; // register prefetch depth: up to 5 x 16 B per lane
 	const bool reg_prefetch = n_vec <= 64 * kMaxVec;
@@ -218,14 +227,14 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 		uint32_t chunk_exit = 0;
 
 		uint64_t a0 = begin & ~15ull; // 16-byte aligned tile base
-		uint4 pre[kMaxVec];
+		u32x4 pre[kMaxVec];
 		auto load_tile_regs = [&](uint64_t base_abs) {
 #pragma unroll
 			for (int i = 0; i < kMaxVec; i++) {
 				const uint32_t v = lane + 64 * i;
 				const uint64_t a = base_abs + (uint64_t)v * 16;
-				uint4 x = make_uint4(0, 0, 0, 0);
-				if (v < n_vec && a + 16 <= readable_end) x = *reinterpret_cast<const uint4 *>(C.bytes + a);
+				u32x4 x = {0, 0, 0, 0};
+				if (v < n_vec && a + 16 <= readable_end) x = *reinterpret_cast<const u32x4 *>(C.bytes + a);
 				pre[i] = x;
 			}
 		};
@@ -239,12 +248,12 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				for (int i = 0; i < kMaxVec; i++) {
 					const uint32_t v = lane + 64 * i;
 					if (v < n_vec) {
-						uint4 x = pre[i];
+						u32x4 x = pre[i];
 						x.x = lower4(x.x);
 						x.y = lower4(x.y);
 						x.z = lower4(x.z);
 						x.w = lower4(x.w);
-						reinterpret_cast<uint4 *>(tile)[v] = x;
+						((LDS_AS u32x4 *)tile)[v] = x;
 					}
 				}
 				const uint64_t next_a0 = a0 + tile_span;
@@ -252,18 +261,17 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			} else {
 				for (uint32_t v = lane; v < n_vec; v += 64) {
 					const uint64_t a = a0 + (uint64_t)v * 16;
-					uint4 x = make_uint4(0, 0, 0, 0);
-					if (a + 16 <= readable_end) x = *reinterpret_cast<const uint4 *>(C.bytes + a);
+					u32x4 x = {0, 0, 0, 0};
+					if (a + 16 <= readable_end) x = *reinterpret_cast<const u32x4 *>(C.bytes + a);
 					x.x = lower4(x.x);
 					x.y = lower4(x.y);
 					x.z = lower4(x.z);
 					x.w = lower4(x.w);
-					reinterpret_cast<uint4 *>(tile)[v] = x;
+					((LDS_AS u32x4 *)tile)[v] = x;
 				}
 			}
 			// ---- document-start bitmap ----
-			for (uint32_t w = lane; w < bm_words; w += 64) bitmap[w] = 0;
-			wave_sync();
+			bool has_bounds = false; // wave uniform: any document start inside the staged bytes
 			{
 				// offsets are sorted, so the ones inside [a0, a0 + tile_cap) are a run starting at
 				// di; di itself advances to the first offset at/after the NEXT tile's base
@@ -271,21 +279,29 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				const uint64_t next_abs = a0 + tile_span;
 				uint64_t scan = di;
 				bool di_done = false;
+				bool zeroed = false;
 				for (;;) {
 					const uint64_t idx = scan + lane;
 					uint64_t o = ~0ull;
 					if (idx <= C.D) o = C.off[idx];
 					const bool in_tile = o < tile_end_abs; // o >= begin >= a0 because idx >= di
+					const unsigned long long in_mask = __ballot(in_tile);
+					if (in_mask && !zeroed) {
+						for (uint32_t w = lane; w < bm_words; w += 64) bitmap[w] = 0;
+						wave_sync();
+						zeroed = true;
+						has_bounds = true;
+					}
 					if (in_tile) {
 						const uint32_t b = (uint32_t)(o - a0);
-						atomicOr(&bitmap[b >> 5], 1u << (b & 31));
+						atomicOr((uint32_t *)&bitmap[b >> 5], 1u << (b & 31));
 					}
 					if (!di_done) {
 						const uint32_t cnt = (uint32_t)__builtin_popcountll(__ballot(o < next_abs));
 						di += cnt;
 						di_done = cnt < 64;
 					}
-					if (__ballot(in_tile) != ~0ull) break;
+					if (in_mask != ~0ull) break;
 					scan += 64;
 				}
 			}
@@ -307,18 +323,19 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			Walker wk;
 			wk.reset(W.root_base);
 			bool active = nonempty && pos < seg_hi;
-			if (active) limit = find_limit(bitmap, pos, stop);
+			if (has_bounds && active) limit = find_limit(bitmap, pos, stop);
 			while (__ballot(active)) {
-				bool done = false;
-				uint32_t len = 0, id = 0;
-				if (active) done = walk_step(W, T, wk, pos, limit, len, id);
-				queue.push(done, id, Qd, lane);
-				if (done) {
-					pos += len;
-					wk.reset(W.root_base);
-					active = pos < seg_hi;
-					if (active && pos >= limit) limit = find_limit(bitmap, pos, stop);
+				if (active) {
+					uint32_t len, id;
+					if (walk_step(W, wk, pos, limit, len, id)) {
+						log.put(lane, id);
+						pos += len;
+						wk.reset(W.root_base);
+						active = pos < seg_hi;
+						if (has_bounds && active && pos >= limit) limit = find_limit(bitmap, pos, stop);
+					}
 				}
+				log.flush_if_full(Qd, lane);
 			}
 			uint32_t cur_exit = nonempty ? pos - seg_hi : 0u;
 
@@ -328,7 +345,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				uint32_t want = __shfl_up(cur_exit, 1, 64);
 				if (lane == 0) want = cur_entry;
 				const bool need = nonempty && want != cur_entry;
-				unsigned long long m = __ballot(need);
+				const unsigned long long m = __ballot(need);
 				if (m == 0) break;
 				// first round: every lane repairs against its neighbour's speculative exit
 				// in parallel (the common case ends here); afterwards strictly in order.
@@ -339,22 +356,23 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				bool walking = mine && (pa < seg_hi || pb < seg_hi);
 				bool on_a = pa < pb;
 				uint32_t lim2 = kNoLimit;
-				if (walking) lim2 = find_limit(bitmap, on_a ? pa : pb, stop);
+				if (has_bounds && walking) lim2 = find_limit(bitmap, on_a ? pa : pb, stop);
 				wk.reset(W.root_base);
 				while (__ballot(walking)) {
-					bool done = false;
-					uint32_t len = 0, id = 0;
-					if (walking) done = walk_step(W, T, wk, on_a ? pa : pb, lim2, len, id);
-					queue.push(done, on_a ? id : (id | Q::neg), Qd, lane);
-					if (done) {
-						if (on_a) pa += len;
-						else pb += len;
-						wk.reset(W.root_base);
-						walking = pa != pb && (pa < seg_hi || pb < seg_hi);
-						on_a = pa < pb;
-						const uint32_t p = on_a ? pa : pb;
-						if (walking && p >= lim2) lim2 = find_limit(bitmap, p, stop);
+					if (walking) {
+						uint32_t len, id;
+						if (walk_step(W, wk, on_a ? pa : pb, lim2, len, id)) {
+							log.put(lane, on_a ? id : (id | Q::neg));
+							if (on_a) pa += len;
+							else pb += len;
+							wk.reset(W.root_base);
+							walking = pa != pb && (pa < seg_hi || pb < seg_hi);
+							on_a = pa < pb;
+							const uint32_t p = on_a ? pa : pb;
+							if (has_bounds && walking && p >= lim2) lim2 = find_limit(bitmap, p, stop);
+						}
 					}
+					log.flush_if_full(Qd, lane);
 				}
 				if (mine) {
 					cur_entry = want;
@@ -374,12 +392,13 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			S.exit_a[j] = chunk_exit;
 		}
 	}
-	queue.finish(Qd, lane);
+	log.finish(Qd, lane);
 }
 
 // ---- token stream -> counts ------------------------------------------------------------
 // grid = (slab_blocks, id_ranges); each workgroup keeps int32 bins for its id range in LDS,
-// consumes its share of the 1 KiB stream blocks, then stores the bins to its slab row.
+// consumes its share of the stream (16-byte vectors, null entries skipped), then stores the
+// bins to its slab row.
 template <bool WIDE>
 __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids, uint32_t range_ids, uint32_t *slab) {
 	using Q = QTraits<WIDE>;
@@ -392,18 +411,19 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 	__syncthreads();
 	uint32_t used = Qd.cursor[0];
 	if (used > Qd.capacity_blocks) used = Qd.capacity_blocks;
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t waves = blockDim.x >> 6;
-	const uint4 *blocks = reinterpret_cast<const uint4 *>(Qd.blocks);
-	for (uint32_t b = blockIdx.x * waves + (threadIdx.x >> 6); b < used; b += gridDim.x * waves) {
-		const uint4 v = blocks[(size_t)b * 64 + lane];
+	constexpr uint32_t vecs_per_block = 64 * kLogDepth * sizeof(typename Q::entry_t) / 16;
+	const uint64_t n_vecs = (uint64_t)used * vecs_per_block;
+	const uint4 *vec = reinterpret_cast<const uint4 *>(Qd.blocks);
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vecs; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint4 v = vec[i];
 		const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
 		for (int k = 0; k < 4; k++) {
+			if (wds[k] == Q::null_word) continue;
 			if (WIDE) {
 				const uint32_t e = wds[k];
 				const uint32_t id = e & 0x7FFFFFFFu;
-				if (id != Q::null_entry && id >= lo && id < hi) atomicAdd(&bins[id - lo], (e & Q::neg) ? 0xFFFFFFFFu : 1u);
+				if (id >= lo && id < hi) atomicAdd(&bins[id - lo], (e & Q::neg) ? 0xFFFFFFFFu : 1u);
 			} else {
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
@@ -433,6 +453,8 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const uint32_t *slab, 
 
 // ---- host side -----------------------------------------------------------------------------
 
+uint32_t stream_block_bytes(uint32_t wide_ids) { return 64 * kLogDepth * (wide_ids ? 4 : 2); }
+
 bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num_cus, TileScanPlan *plan) {
 	static const uint32_t kSeg[] = {68, 132, 260, 516, 1028};
 	uint32_t seg = 0;
@@ -457,8 +479,7 @@ bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num
 		const uint32_t tile_cap = 64 * seg + halo + 16;
 		const uint32_t n_vec = (tile_cap + 15) / 16;
 		const uint32_t bm_words = (tile_cap + 31) / 32 + 1;
-		const uint32_t q_entries = (wide ? kQueueFlush32 : kQueueFlush16) + 64;
-		wave_bytes = n_vec * 16 + ((bm_words * 4 + 15) & ~15u) + ((q_entries * (wide ? 4 : 2) + 15) & ~15u);
+		wave_bytes = n_vec * 16 + ((bm_words * 4 + 15) & ~15u) + stream_block_bytes(wide);
 		if ((uint64_t)wave_bytes * waves + 8 * 1024 <= lds_total) break;
 		if (waves == 1) return false;
 		waves >>= 1; // long segments: fewer waves so that the tiles still fit

@@ -69,6 +69,7 @@ struct tokscore_ctx {
 	// plan
 	bool plan_valid = false;
 	int scan_path = 0; // 0 generic, 1 tile
+	bool force_generic = false; // set after a token-stream overflow
 	TileScanPlan tile = {};
 	uint64_t chunk_bytes = 0;
 	std::vector<uint64_t> h_chunk_begin;
@@ -154,13 +155,11 @@ void build_chunks(tokscore_ctx *c, uint64_t chunk_bytes) {
 
 TrieDev trie_dev(const tokscore_ctx *c) {
 	TrieDev T;
-	T.slots = c->d_slots;
+	T.slots = reinterpret_cast<const uint2 *>(c->d_slots);
 	T.nslots = (uint32_t)c->packed.slots.size();
-	T.slot_bits = c->packed.slot_bits;
-	T.pmask = c->packed.pmask();
-	T.id_shift = 2 * c->packed.slot_bits;
 	T.unknown_id = c->packed.unknown_id;
 	T.lds_slots = c->tile.lds_slots;
+	T.root_base = c->packed.slots.empty() ? 0 : PackedTrie::base(c->packed.slots[0]);
 	return T;
 }
 
@@ -201,6 +200,7 @@ int ensure_plan(tokscore_ctx *c) {
 	TrieDev T = trie_dev(c);
 	bool tile_ok = plan_tile_scan(T, c->packed.max_len, (uint32_t)c->V, (uint32_t)c->num_cus, &c->tile);
 	if (force && !strcmp(force, "generic")) tile_ok = false;
+	if (c->force_generic) tile_ok = false;
 	c->scan_path = tile_ok ? 1 : 0;
 	if (!tile_ok) c->tile = TileScanPlan{};
 	uint64_t dflt_chunk = 2048;
@@ -227,16 +227,17 @@ int ensure_plan(tokscore_ctx *c) {
 	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, 64));
 	if (c->scan_path == 1) {
-		// Token stream: <= 1 entry per corpus byte from the speculative pass, <= 2 per byte
-		// from the parallel repair round and <= 2 per byte from the ordered round, plus one
-		// partly filled 1 KiB block per wave.
+		// Token stream: one entry per emitted token plus the repair rounds' +/- entries, in
+		// log blocks that are partly empty.  3 entries per corpus byte is far above anything
+		// but adversarial input; an overflow is detected and the evaluation redone on the
+		// generic path, never silently truncated.
 		const uint64_t entry_bytes = c->tile.wide_ids ? 4 : 2;
-		const uint64_t entries = 5 * c->total + 1024;
+		const uint64_t block_bytes = stream_block_bytes(c->tile.wide_ids);
 		const uint64_t waves = (uint64_t)c->tile.blocks * c->tile.waves_per_block;
-		const uint64_t blocks = (entries * entry_bytes + 1023) / 1024 + 2 * waves + 16;
+		const uint64_t blocks = (3 * c->total * entry_bytes) / block_bytes + 2 * waves + 16;
 		if (blocks > 0xFFFFFFF0ull) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one token stream");
 		c->stream_cap_blocks = (uint32_t)blocks;
-		HIP_TRY(c, hipMalloc(&c->d_stream, blocks * 1024));
+		HIP_TRY(c, hipMalloc(&c->d_stream, blocks * block_bytes));
 		c->slab_blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, c->total / (256 * 1024)));
 		HIP_TRY(c, hipMalloc((void **)&c->d_slab, (size_t)c->slab_blocks * (c->V + 3) * sizeof(uint32_t)));
 	}
@@ -461,6 +462,7 @@ int tokscore_set_corpus(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *o
 		}
 	}
 	c->sample_used = false;
+	c->force_generic = false;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	c->corpus_set = true;
 	return TOKSCORE_OK;
@@ -515,6 +517,12 @@ int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, ui
 	HIP_TRY(c, hipMemcpyAsync(host.data(), c->d_out, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	st = check_overflow(c);
+	if (st == TOKSCORE_E_CAPACITY && !c->force_generic) {
+		// adversarial input blew the stream bound: redo this evaluation on the generic path
+		c->force_generic = true;
+		c->plan_valid = false;
+		return tokscore_score(c, counts, total_tokens, total_bytes);
+	}
 	if (st) return st;
 	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
 	if (total_tokens) *total_tokens = host[c->V + 3];
@@ -572,8 +580,8 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 	}
 	if (c->packed_valid) {
 		info->trie_slots = c->packed.slots.size();
-		info->slot_bits = c->packed.slot_bits;
-		info->id_bits = c->packed.id_bits;
+		info->slot_bits = 23;
+		info->id_bits = 32;
 	}
 	info->corpus_bytes = c->total;
 	info->corpus_docs = c->D;

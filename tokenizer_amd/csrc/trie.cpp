@@ -12,14 +12,6 @@ inline uint8_t ascii_lower(uint8_t c) {
 	// std::tolower in the "C" locale (SolutionFile.cpp:87-88): A-Z only.
 	return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c;
 }
-inline uint32_t bit_width(uint64_t x) {
-	uint32_t b = 0;
-	while (x) {
-		b++;
-		x >>= 1;
-	}
-	return b;
-}
 } // namespace
 
 bool VocabTrie::Build(const uint8_t *bytes, const uint64_t *off, uint64_t V, std::string *err) {
@@ -170,9 +162,14 @@ bool VocabTrie::Pack(PackedTrie *out, std::string *err) {
 	}
 	parents.insert(parents.begin(), 0u); // the root always goes first
 
-	std::vector<uint8_t> used(1024, 0);
+	std::vector<uint8_t> used(1024, 0);      // slot occupied
+	std::vector<uint8_t> base_used(1024, 0); // value already serves as some node's base
 	auto ensure = [&](uint64_t n) {
-		if (used.size() < n) used.resize(std::max<uint64_t>(n, used.size() * 2), 0);
+		if (used.size() < n) {
+			const uint64_t m = std::max<uint64_t>(n, used.size() * 2);
+			used.resize(m, 0);
+			base_used.resize(m, 0);
+		}
 	};
 	node_slot_.assign(N, 0);
 	std::vector<uint32_t> node_base(N, 0);
@@ -184,22 +181,18 @@ bool VocabTrie::Pack(PackedTrie *out, std::string *err) {
 		const uint32_t nc = n_children_[node];
 		const uint32_t c0 = e[0].byte;
 		while (first_free < used.size() && used[first_free]) first_free++;
-		// smallest base b >= 1 with every slot b + c free
+		// smallest unused base b >= 1 with every slot b + c free
 		uint64_t b = first_free > c0 ? first_free - c0 : 1;
 		for (;;) {
 			ensure(b + 257);
-			bool ok = true;
-			for (uint32_t k = 0; k < nc; k++) {
-				if (used[b + e[k].byte]) {
-					ok = false;
-					break;
-				}
-			}
+			bool ok = !base_used[b];
+			for (uint32_t k = 0; ok && k < nc; k++) ok = !used[b + e[k].byte];
 			if (ok) break;
 			b++;
 			// skip ahead to the next base whose first child slot is free
 			while (b + c0 < used.size() && used[b + c0]) b++;
 		}
+		base_used[b] = 1;
 		node_base[node] = (uint32_t)b;
 		for (uint32_t k = 0; k < nc; k++) {
 			used[b + e[k].byte] = 1;
@@ -208,33 +201,24 @@ bool VocabTrie::Pack(PackedTrie *out, std::string *err) {
 		}
 	}
 	const uint64_t nslots = max_used + 1 + 256; // base + 255 is always a readable slot
-	const uint32_t sb = bit_width(nslots);      // (1<<sb)-1 >= nslots: never a valid slot
-	const uint32_t ib = std::max<uint32_t>(1, bit_width(V_ + 1));
-	if (2 * sb + ib > 64 || sb > 31) {
-		if (err) *err = "vocabulary too large for the packed trie entry (2*slot_bits + id_bits > 64)";
+	if (nslots > PackedTrie::kMaxSlots) {
+		if (err) *err = "vocabulary too large for the packed trie (more than 2^23 slots)";
 		return false;
 	}
-	out->slot_bits = sb;
-	out->id_bits = ib;
 	out->nodes = N;
 	out->max_len = max_len_;
 	out->unknown_id = (uint32_t)(V_ + 2);
-	const uint64_t pm = (1ull << sb) - 1;
-	out->slots.assign(nslots, pm); // empty: parent = all ones, base = 0, id = 0
+	out->slots.assign(nslots, 0); // empty: valid = 0, base = 0, id = 0
 	for (uint32_t node = 0; node < N; node++) {
-		const uint32_t slot = node_slot_[node];
-		uint64_t entry = (node == 0) ? pm : 0; // parent filled in below for non-root nodes
-		entry |= (uint64_t)node_base[node] << sb;
-		entry |= (uint64_t)ActiveId(node) << (2 * sb);
-		out->slots[slot] = entry; // slot 0 for the root; unique per node otherwise
+		uint64_t entry = (uint64_t)node_base[node] << PackedTrie::kBaseShift; // root: valid = 0
+		entry |= (uint64_t)ActiveId(node) << 32;
+		out->slots[node_slot_[node]] = entry; // slot 0 for the root; unique per node otherwise
 	}
-	// parent fields: walk the edges
+	// label + valid: walk the edges
 	for (uint32_t node = 0; node < N; node++) {
 		const Edge *e = edges_.data() + first_child_[node];
-		for (uint32_t k = 0; k < n_children_[node]; k++) {
-			const uint32_t cs = node_slot_[e[k].child];
-			out->slots[cs] = (out->slots[cs] & ~pm) | node_slot_[node];
-		}
+		for (uint32_t k = 0; k < n_children_[node]; k++)
+			out->slots[node_slot_[e[k].child]] |= (uint64_t)(PackedTrie::kValid | e[k].byte);
 	}
 	return true;
 }
@@ -245,9 +229,7 @@ int64_t VocabTrie::Toggle(uint64_t token, bool enable, PackedTrie *packed, uint6
 	const uint32_t node = tok_node_[token];
 	if (node == 0 || node_slot_.empty()) return -1; // empty string, or not packed yet
 	const uint32_t slot = node_slot_[node];
-	const uint32_t sb = packed->slot_bits;
-	const uint64_t keep = (sb == 32) ? ~0ull : ((1ull << (2 * sb)) - 1);
-	const uint64_t e = (packed->slots[slot] & keep) | ((uint64_t)ActiveId(node) << (2 * sb));
+	const uint64_t e = (packed->slots[slot] & 0xFFFFFFFFull) | ((uint64_t)ActiveId(node) << 32);
 	if (e == packed->slots[slot]) return -1;
 	packed->slots[slot] = e;
 	*new_entry = e;
@@ -257,17 +239,15 @@ int64_t VocabTrie::Toggle(uint64_t token, bool enable, PackedTrie *packed, uint6
 void VocabTrie::Longest(const PackedTrie &p, const uint8_t *text, uint64_t n, uint64_t *len, uint64_t *id) {
 	*len = 0;
 	*id = 0;
-	uint32_t node = 0;
-	uint32_t base = p.base(p.slots[0]);
+	uint32_t base = PackedTrie::base(p.slots[0]);
 	for (uint64_t d = 0; d < n && base; d++) {
-		const uint32_t t = base + ascii_lower(text[d]);
-		const uint64_t e = p.slots[t];
-		if (p.parent(e) != node) break;
-		node = t;
-		base = p.base(e);
-		if (p.id(e)) {
+		const uint32_t c = ascii_lower(text[d]);
+		const uint64_t e = p.slots[base + c];
+		if (!PackedTrie::matches(e, c)) break;
+		base = PackedTrie::base(e);
+		if (PackedTrie::id(e)) {
 			*len = d + 1;
-			*id = p.id(e);
+			*id = PackedTrie::id(e);
 		}
 	}
 }

@@ -14,24 +14,30 @@
 
 namespace tokscore {
 
-// Packed slot t (one byte-trie node), little end first:
-//   parent : slot_bits   slot index of the parent node (all ones = empty slot)
-//   base   : slot_bits   children live at slot base + byte; 0 = leaf
-//   id     : id_bits     id emitted when a match ends here (token index + 2); 0 = none
-// Slot 0 is the root.  A lookup of byte c under node n reads slot t = base(n) + c and
-// hits iff parent(t) == n, so hits AND misses cost exactly one 8-byte read.
+// Packed slot t (one byte-trie node), two 32-bit words:
+//   w0 = label : 8   the byte on the edge from the parent
+//        valid : 1   0 for empty slots and for the root
+//        base  : 23  children live at slot base + byte; 0 = leaf
+//   w1 = id          id emitted when a match ends here (token index + 2); 0 = none
+// Slot 0 is the root.  Every non-leaf node has a base of its own (no two nodes share
+// one), so a slot's owner is identified by base = t - label alone: a lookup of byte c
+// under a node with base b reads slot t = b + c and hits iff that slot is valid and its
+// label is c.  Hits AND misses cost exactly one 8-byte read and a 9-bit compare.
 struct PackedTrie {
+	static constexpr uint32_t kValid = 0x100u;
+	static constexpr uint32_t kKeyMask = 0x1FFu;
+	static constexpr uint32_t kBaseShift = 9;
+	static constexpr uint64_t kMaxSlots = 1ull << 23;
+
 	std::vector<uint64_t> slots;
-	uint32_t slot_bits = 0;
-	uint32_t id_bits = 0;
 	uint64_t nodes = 0;
 	uint64_t max_len = 0;    // SolutionFile::max_len_ (bytes), duplicates included
 	uint32_t unknown_id = 0; // V + 2
 
-	uint32_t pmask() const { return slot_bits >= 32 ? 0xFFFFFFFFu : ((1u << slot_bits) - 1u); }
-	uint32_t parent(uint64_t e) const { return (uint32_t)(e & pmask()); }
-	uint32_t base(uint64_t e) const { return (uint32_t)((e >> slot_bits) & pmask()); }
-	uint32_t id(uint64_t e) const { return (uint32_t)(e >> (2 * slot_bits)); }
+	static uint32_t w0(uint64_t e) { return (uint32_t)e; }
+	static uint32_t base(uint64_t e) { return (uint32_t)e >> kBaseShift; }
+	static uint32_t id(uint64_t e) { return (uint32_t)(e >> 32); }
+	static bool matches(uint64_t e, uint32_t c) { return ((uint32_t)e & kKeyMask) == (c | kValid); }
 };
 
 class VocabTrie {
@@ -45,7 +51,7 @@ public:
 	// steers the layout, never results) and count the lookups made at every node.
 	void AddHotnessSample(const uint8_t *sample, uint64_t n);
 
-	// Flatten to the double array.  Returns false when 2*slot_bits + id_bits > 64.
+	// Flatten to the double array.  Returns false when it would need more than 2^23 slots.
 	bool Pack(PackedTrie *out, std::string *err);
 
 	// Enable/disable token i; returns the slot whose id field changed (or -1) and the
