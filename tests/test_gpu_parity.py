@@ -146,7 +146,7 @@ def test_long_tokens_fall_back_to_generic_scan():
 
 def test_toggle_equals_full_rescore_of_the_toggled_vocabulary():
     corpus, off = synth.cjk_heavy(400_000, seed=9)
-    tokens = synth.build_vocab(corpus[:200_000], 3000)
+    tokens = synth.build_vocab(corpus[:200_000], 9000)
     V = len(tokens)
     s = ta.Scorer(0)
     s.set_vocab(*synth.pack_vocab(tokens))
@@ -155,6 +155,7 @@ def test_toggle_equals_full_rescore_of_the_toggled_vocabulary():
     rng = np.random.default_rng(5)
     enabled = np.ones(V, dtype=bool)
     multi = [i for i, t in enumerate(tokens) if len(t.decode("utf-8")) > 1]
+    assert multi, "vocabulary has no multi-character tokens"
     for step in range(12):
         i = int(rng.choice(multi))
         enabled[i] = not enabled[i]

@@ -23,10 +23,17 @@ struct TileScanPlan {
 	uint32_t blocks;          // persistent workgroups
 	uint32_t wide_ids;        // 0: 16-bit stream entries, 1: 32-bit
 };
+// Token stream and work-queue words shared by the tile scan and the histogram.
+constexpr uint32_t kStreamBatch = 32;     // stream blocks handed out per allocation
+constexpr uint32_t kWorkQueues = 64;      // sharded chunk-queue heads
+constexpr uint32_t kQueueHeadWord = 32;   // first head at cursor[32], one per 128-byte line
+constexpr uint32_t kQueueHeadStride = 32;
+constexpr uint32_t kCursorWords = kQueueHeadWord + kWorkQueues * kQueueHeadStride;
 struct StreamDev {
-	void *blocks;              // token stream, blocks of stream_block_bytes()
-	uint32_t capacity_blocks;
-	uint32_t *cursor;          // [0] blocks handed out, [1] overflow flag, [2] next work chunk
+	void *blocks;               // token stream, blocks of stream_block_bytes()
+	uint32_t capacity_batches;  // batches of kStreamBatch blocks
+	uint32_t *fill;             // [capacity_batches] blocks written per batch
+	uint32_t *cursor;           // [0] batches handed out, [1] overflow flag, [kQueueHeadWord + q*stride] queue heads
 };
 uint32_t stream_block_bytes(uint32_t wide_ids);
 bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num_cus, TileScanPlan *plan);

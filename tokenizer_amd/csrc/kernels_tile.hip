@@ -96,20 +96,30 @@ template <bool WIDE> struct LaneLog {
 		cells[k * 64 + lane] = (typename Q::entry_t)val;
 		k++;
 	}
+	// Stream space is handed out in batches of kStreamBatch blocks, so the single
+	// allocation word sees one atomic per batch, not per block (one word sustains only
+	// ~90 atomics/us chip-wide).  fill[batch] records how many blocks of a batch hold data.
+	uint32_t batch = 0xFFFFFFFFu; // wave uniform
+	uint32_t used = kStreamBatch; // wave uniform: blocks written in the current batch
+
 	// wave-uniform call: send the block out and start an empty one
 	__device__ __forceinline__ void flush(const StreamDev &S, uint32_t lane) {
 		constexpr uint32_t vecs = 64 * kLogDepth * sizeof(typename Q::entry_t) / 16; // 16-byte vectors
-		uint32_t blk = 0;
-		if (lane == 0) blk = atomicAdd(&S.cursor[0], 1u);
-		blk = __builtin_amdgcn_readfirstlane(blk);
-		wave_sync();
-		if (blk < S.capacity_blocks) {
-			const LDS_AS u32x4 *src = (const LDS_AS u32x4 *)cells;
-			u32x4 *dst = reinterpret_cast<u32x4 *>(S.blocks) + (size_t)blk * vecs;
-			for (uint32_t i = lane; i < vecs; i += 64) dst[i] = src[i];
-		} else if (lane == 0) {
-			S.cursor[1] = 1u; // overflow: reported by the host, never silently dropped
+		if (used == kStreamBatch) {
+			if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = kStreamBatch;
+			uint32_t b = 0;
+			if (lane == 0) b = atomicAdd(&S.cursor[0], 1u);
+			batch = __builtin_amdgcn_readfirstlane(b);
+			used = 0;
+			if (batch >= S.capacity_batches && lane == 0) S.cursor[1] = 1u; // overflow: reported, never dropped silently
 		}
+		wave_sync();
+		if (batch < S.capacity_batches) {
+			const LDS_AS u32x4 *src = (const LDS_AS u32x4 *)cells;
+			u32x4 *dst = reinterpret_cast<u32x4 *>(S.blocks) + ((size_t)batch * kStreamBatch + used) * vecs;
+			for (uint32_t i = lane; i < vecs; i += 64) dst[i] = src[i];
+		}
+		used++;
 		wave_sync();
 		clear(lane);
 		wave_sync();
@@ -119,6 +129,7 @@ template <bool WIDE> struct LaneLog {
 	}
 	__device__ __forceinline__ void finish(const StreamDev &S, uint32_t lane) {
 		if (__ballot(k != 0)) flush(S, lane);
+		if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = used;
 	}
 };
 
@@ -211,14 +222,17 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	W.root_base = T.root_base;
 	W.unknown_id = T.unknown_id;
 
+	const uint32_t queue = blockIdx.x % kWorkQueues;
 	constexpr int kMaxVec = 5; // register prefetch depth: up to 5 x 16 B per lane
 	const bool reg_prefetch = n_vec <= 64 * kMaxVec;
 
 	for (;;) {
 		// ---- next work chunk ----
+		// work queue sharded over kWorkQueues heads (one 128-byte line each): chunk j belongs
+		// to head j % kWorkQueues, workgroup b pulls from head b % kWorkQueues
 		uint32_t j = 0;
-		if (lane == 0) j = atomicAdd(&Qd.cursor[2], 1u);
-		j = __builtin_amdgcn_readfirstlane(j);
+		if (lane == 0) j = atomicAdd(&Qd.cursor[kQueueHeadWord + queue * kQueueHeadStride], 1u);
+		j = __builtin_amdgcn_readfirstlane(j) * kWorkQueues + queue;
 		if (j >= S.nchunks) break;
 		const uint64_t begin = S.begin[j];
 		const uint64_t end = S.begin[j + 1];
@@ -409,12 +423,16 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 	const uint32_t width = hi - lo;
 	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) bins[i] = 0;
 	__syncthreads();
-	uint32_t used = Qd.cursor[0];
-	if (used > Qd.capacity_blocks) used = Qd.capacity_blocks;
+	uint32_t batches = Qd.cursor[0];
+	if (batches > Qd.capacity_batches) batches = Qd.capacity_batches;
 	constexpr uint32_t vecs_per_block = 64 * kLogDepth * sizeof(typename Q::entry_t) / 16;
-	const uint64_t n_vecs = (uint64_t)used * vecs_per_block;
+	constexpr uint32_t vecs_per_batch = vecs_per_block * kStreamBatch;
+	const uint64_t n_vecs = (uint64_t)batches * vecs_per_batch;
 	const uint4 *vec = reinterpret_cast<const uint4 *>(Qd.blocks);
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vecs; i += (uint64_t)gridDim.x * blockDim.x) {
+		// blocks past fill[batch] were handed out but never written
+		const uint32_t bt = (uint32_t)(i / vecs_per_batch);
+		if ((uint32_t)(i % vecs_per_batch) / vecs_per_block >= Qd.fill[bt]) continue;
 		const uint4 v = vec[i];
 		const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll

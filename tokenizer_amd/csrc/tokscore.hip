@@ -78,7 +78,8 @@ struct tokscore_ctx {
 	uint32_t *d_chunk_state = nullptr; // entry | exit_a | exit_b
 	uint32_t nchunks = 0;
 	void *d_stream = nullptr;
-	uint32_t stream_cap_blocks = 0;
+	uint32_t stream_cap_batches = 0;
+	uint32_t *d_fill = nullptr;
 	uint32_t *d_cursor = nullptr;
 	uint32_t *d_slab = nullptr;
 	uint32_t slab_blocks = 0;
@@ -123,6 +124,8 @@ void free_plan(tokscore_ctx *c) {
 	c->d_chunk_first_doc = nullptr;
 	if (c->d_stream) (void)hipFree(c->d_stream);
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
+	if (c->d_fill) (void)hipFree(c->d_fill);
+	c->d_fill = nullptr;
 	if (c->d_slab) (void)hipFree(c->d_slab);
 	c->d_chunk_begin = nullptr;
 	c->d_chunk_state = nullptr;
@@ -225,7 +228,7 @@ int ensure_plan(tokscore_ctx *c) {
 		HIP_TRY(c, hipMalloc((void **)&c->d_chunk_first_doc, first.size() * sizeof(uint64_t)));
 		HIP_TRY(c, hipMemcpy(c->d_chunk_first_doc, first.data(), first.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	}
-	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, 64));
+	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, kCursorWords * sizeof(uint32_t)));
 	if (c->scan_path == 1) {
 		// Token stream: one entry per emitted token plus the repair rounds' +/- entries, in
 		// log blocks that are partly empty.  3 entries per corpus byte is far above anything
@@ -234,10 +237,11 @@ int ensure_plan(tokscore_ctx *c) {
 		const uint64_t entry_bytes = c->tile.wide_ids ? 4 : 2;
 		const uint64_t block_bytes = stream_block_bytes(c->tile.wide_ids);
 		const uint64_t waves = (uint64_t)c->tile.blocks * c->tile.waves_per_block;
-		const uint64_t blocks = (3 * c->total * entry_bytes) / block_bytes + 2 * waves + 16;
-		if (blocks > 0xFFFFFFF0ull) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one token stream");
-		c->stream_cap_blocks = (uint32_t)blocks;
-		HIP_TRY(c, hipMalloc(&c->d_stream, blocks * block_bytes));
+		const uint64_t batches = (3 * c->total * entry_bytes) / (block_bytes * kStreamBatch) + 2 * waves + 16;
+		if (batches > 0x7FFFFFF0ull) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one token stream");
+		c->stream_cap_batches = (uint32_t)batches;
+		HIP_TRY(c, hipMalloc(&c->d_stream, batches * kStreamBatch * block_bytes));
+		HIP_TRY(c, hipMalloc((void **)&c->d_fill, batches * sizeof(uint32_t)));
 		c->slab_blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, c->total / (256 * 1024)));
 		HIP_TRY(c, hipMalloc((void **)&c->d_slab, (size_t)c->slab_blocks * (c->V + 3) * sizeof(uint32_t)));
 	}
@@ -272,8 +276,9 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	HIP_TRY(c, hipEventRecord(c->ev[0], s));
 	HIP_TRY(c, hipMemsetAsync(d_out, 0, (c->V + 5) * sizeof(unsigned long long), s));
 	if (c->scan_path == 1) {
-		HIP_TRY(c, hipMemsetAsync(c->d_cursor, 0, 64, s));
-		StreamDev Q{c->d_stream, c->stream_cap_blocks, c->d_cursor};
+		HIP_TRY(c, hipMemsetAsync(c->d_cursor, 0, kCursorWords * sizeof(uint32_t), s));
+		HIP_TRY(c, hipMemsetAsync(c->d_fill, 0, (size_t)c->stream_cap_batches * sizeof(uint32_t), s));
+		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 		HIP_TRY(c, hipEventRecord(c->ev[1], s));
 		launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s);
 		HIP_TRY(c, hipEventRecord(c->ev[2], s));
