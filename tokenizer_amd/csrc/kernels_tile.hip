@@ -154,33 +154,26 @@ struct Walker {
 	}
 };
 
-// One trie lookup for the token that started at pos.  Returns true when the token is
-// complete (miss, window clipped, or a leaf was reached); then len/id hold it.
-__device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t pos, uint32_t limit, uint32_t &len,
-                                          uint32_t &id) {
-	const uint32_t q = pos + w.d;
-	bool more = false;
-	if (q < limit) {
-		const uint32_t c = W.tile[q];
-		const uint32_t t = w.base + c;
-		u32x2 e;
-		if (t < W.lds_slots) e = W.lds_trie[t];
-		else e = W.g_trie[t];
-		if ((e.x & kSlotKeyMask) == (c | kSlotValid)) {
-			w.d++;
-			w.base = e.x >> kSlotBaseShift;
-			if (e.y) {
-				w.last_len = w.d;
-				w.last_id = e.y;
-			}
-			more = w.base != 0; // a leaf ends the token without another lookup
-		}
-	}
-	if (more) return false;
-	// SolutionFile.cpp:92-94: nothing matched down to len 1 -> UNKNOWN, advance one byte
-	len = w.last_len ? w.last_len : 1u;
-	id = w.last_len ? w.last_id : W.unknown_id;
-	return true;
+// One trie lookup for the token that started at pos, written without divergent branches
+// (the kernel is instruction-issue bound: every exec-mask round trip costs).  Every lane
+// executes it; `on` = this lane has a token in progress.  Returns true when the token is
+// complete (miss, window clipped at `limit`, or a leaf was reached); then w.last_len /
+// w.last_id describe it (last_len == 0: UNKNOWN, SolutionFile.cpp:92-94).
+__device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, bool on, uint32_t pos, uint32_t limit) {
+	const uint32_t q = pos + w.d; // < tile_cap for every lane, finished ones included
+	const uint32_t c = W.tile[q];
+	const uint32_t t = w.base + c;
+	const uint32_t tl = t < W.lds_slots ? t : 0u;
+	u32x2 e = W.lds_trie[tl];
+	if (t >= W.lds_slots) e = W.g_trie[t]; // cold slot: L2 (t < nslots: base + 255 is always in range)
+	const bool hit = on && q < limit && (e.x & kSlotKeyMask) == (c | kSlotValid);
+	const uint32_t nbase = e.x >> kSlotBaseShift;
+	w.d += hit ? 1u : 0u;
+	w.base = hit ? nbase : w.base;
+	const bool term = hit && e.y != 0;
+	w.last_len = term ? w.d : w.last_len;
+	w.last_id = term ? e.y : w.last_id;
+	return on && !(hit && nbase != 0); // a leaf ends the token without another lookup
 }
 
 template <bool WIDE>
@@ -223,6 +216,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	W.unknown_id = T.unknown_id;
 
 	const uint32_t queue = blockIdx.x % kWorkQueues;
+	const uint32_t min_seg = 4 * (((max_len + 4 + 3) / 4) | 1u); // shortest legal lane segment
 	constexpr int kMaxVec = 5; // register prefetch depth: up to 5 x 16 B per lane
 	const bool reg_prefetch = n_vec <= 64 * kMaxVec;
 
@@ -325,9 +319,18 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			const uint32_t off0 = (uint32_t)(begin > a0 ? begin - a0 : 0); // only the chunk's first tile
 			const uint64_t rem = end - a0;
 			const uint32_t tile_hi = rem < tile_span ? (uint32_t)rem : tile_span;
-			const uint32_t seg_nom = lane * seg_bytes;
+			// a chunk's last, partial tile is cut into shorter segments (still 4 * odd bytes and
+			// longer than any token) so that as many lanes as possible share it
+			uint32_t seg_t = seg_bytes;
+			if (tile_hi < tile_span) {
+				const uint32_t dw = ((tile_hi + 63) / 64 + 3) / 4;
+				seg_t = 4 * (dw | 1u);
+				if (seg_t < min_seg) seg_t = min_seg;
+				if (seg_t > seg_bytes) seg_t = seg_bytes;
+			}
+			const uint32_t seg_nom = lane * seg_t;
 			uint32_t seg_lo = seg_nom > off0 ? seg_nom : off0;
-			uint32_t seg_hi = seg_nom + seg_bytes < tile_hi ? seg_nom + seg_bytes : tile_hi;
+			uint32_t seg_hi = seg_nom + seg_t < tile_hi ? seg_nom + seg_t : tile_hi;
 			const bool nonempty = seg_lo < seg_hi;
 			if (!nonempty) seg_hi = seg_lo;
 			const uint32_t stop = seg_hi + max_len; // no walk of this segment reads at/after stop
@@ -339,14 +342,19 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			bool active = nonempty && pos < seg_hi;
 			if (has_bounds && active) limit = find_limit(bitmap, pos, stop);
 			while (__ballot(active)) {
-				if (active) {
-					uint32_t len, id;
-					if (walk_step(W, wk, pos, limit, len, id)) {
-						log.put(lane, id);
-						pos += len;
-						wk.reset(W.root_base);
-						active = pos < seg_hi;
-						if (has_bounds && active && pos >= limit) limit = find_limit(bitmap, pos, stop);
+				const bool fin = walk_step(W, wk, active, pos, limit);
+				const uint32_t id = wk.last_len ? wk.last_id : W.unknown_id;
+				const uint32_t len = wk.last_len ? wk.last_len : 1u;
+				if (fin) log.put(lane, id);
+				pos += fin ? len : 0u;
+				wk.d = fin ? 0u : wk.d;
+				wk.base = fin ? W.root_base : wk.base;
+				wk.last_len = fin ? 0u : wk.last_len;
+				active = pos < seg_hi;
+				if (has_bounds) {
+					const bool cross = active && pos >= limit;
+					if (__ballot(cross)) {
+						if (cross) limit = find_limit(bitmap, pos, stop);
 					}
 				}
 				log.flush_if_full(Qd, lane);
@@ -373,17 +381,22 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				if (has_bounds && walking) lim2 = find_limit(bitmap, on_a ? pa : pb, stop);
 				wk.reset(W.root_base);
 				while (__ballot(walking)) {
-					if (walking) {
-						uint32_t len, id;
-						if (walk_step(W, wk, on_a ? pa : pb, lim2, len, id)) {
-							log.put(lane, on_a ? id : (id | Q::neg));
-							if (on_a) pa += len;
-							else pb += len;
-							wk.reset(W.root_base);
-							walking = pa != pb && (pa < seg_hi || pb < seg_hi);
-							on_a = pa < pb;
-							const uint32_t p = on_a ? pa : pb;
-							if (has_bounds && walking && p >= lim2) lim2 = find_limit(bitmap, p, stop);
+					const bool fin = walk_step(W, wk, walking, on_a ? pa : pb, lim2);
+					const uint32_t id = wk.last_len ? wk.last_id : W.unknown_id;
+					const uint32_t len = wk.last_len ? wk.last_len : 1u;
+					if (fin) log.put(lane, on_a ? id : (id | Q::neg));
+					pa += (fin && on_a) ? len : 0u;
+					pb += (fin && !on_a) ? len : 0u;
+					wk.d = fin ? 0u : wk.d;
+					wk.base = fin ? W.root_base : wk.base;
+					wk.last_len = fin ? 0u : wk.last_len;
+					walking = walking && pa != pb && (pa < seg_hi || pb < seg_hi);
+					on_a = pa < pb;
+					if (has_bounds) {
+						const uint32_t p = on_a ? pa : pb;
+						const bool cross = walking && p >= lim2;
+						if (__ballot(cross)) {
+							if (cross) lim2 = find_limit(bitmap, p, stop);
 						}
 					}
 					log.flush_if_full(Qd, lane);

@@ -210,7 +210,10 @@ int ensure_plan(tokscore_ctx *c) {
 	if (tile_ok) {
 		// a few chunks per resident wave, so the atomic work queue can balance the tail
 		const uint64_t waves = (uint64_t)c->tile.blocks * c->tile.waves_per_block;
-		dflt_chunk = std::min<uint64_t>(64u * 1024u, std::max<uint64_t>(8u * 1024u, c->total / (waves * 4)));
+		// and a whole number of tiles per chunk, so that only snapped chunks end in a partial tile
+		const uint64_t tile_span = 64ull * c->tile.seg_bytes;
+		const uint64_t tiles = std::min<uint64_t>(16, std::max<uint64_t>(2, c->total / (waves * 4) / tile_span));
+		dflt_chunk = tiles * tile_span;
 	}
 	c->chunk_bytes = env_u64("TOKSCORE_CHUNK", dflt_chunk);
 	if (c->chunk_bytes < 64) c->chunk_bytes = 64;

@@ -17,17 +17,18 @@ from tokenizer_amd import synth  # noqa: E402
 def main():
     mb = float(sys.argv[1]) if len(sys.argv) > 1 else 100.0
     vocab_src, _ = synth.wiki_like(2_000_000, seed=20201120)
-    tokens = synth.build_vocab(vocab_src, 32000)
+    tokens = synth.build_vocab(vocab_src, int(os.environ.get("SWEEP_VOCAB", "32000")))
     corpus, off = synth.wiki_like(int(mb * 1e6), seed=20201120)
     tb, to = synth.pack_vocab(tokens)
     ref = None
     configs = []
-    for seg, waves in itertools.product(("68", "132", "260"), ("16", "8", "4")):
-        configs.append({"TOKSCORE_SEG": seg, "TOKSCORE_WAVES": waves})
+    if not sys.argv[2:]:
+        for seg, waves in itertools.product(("68", "132", "260"), ("16", "8", "4")):
+            configs.append({"TOKSCORE_SEG": seg, "TOKSCORE_WAVES": waves})
     for extra in sys.argv[2:]:
         configs.append(dict(kv.split("=") for kv in extra.split(",")))
     for cfg in configs:
-        for k in ("TOKSCORE_SEG", "TOKSCORE_WAVES", "TOKSCORE_LDS_SLOTS", "TOKSCORE_CHUNK", "TOKSCORE_SCAN"):
+        for k in ("TOKSCORE_SEG", "TOKSCORE_WAVES", "TOKSCORE_LDS_SLOTS", "TOKSCORE_CHUNK", "TOKSCORE_SCAN", "TOKSCORE_COLD_THRESH"):
             os.environ.pop(k, None)
         os.environ.update(cfg)
         s = ta.Scorer(0)
