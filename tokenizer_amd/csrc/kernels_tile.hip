@@ -16,7 +16,7 @@
 //            column of the wave's LDS log block (no cross-lane traffic);
 //   phase 2  lane k's true entry is lane k-1's exit overshoot.  Lanes whose guess (0) was
 //            wrong dual-walk the true chain (+ entries) against the guessed one (- entries)
-//            until the chains meet; exits that change are settled in lane order.
+//            until the chains meet; rounds repeat while some exit still moves.
 // A log block goes to HBM whenever one lane's column is full (unused cells are null
 // entries); hist_kernel turns the stream into counts with an LDS histogram per workgroup.
 // Results equal the serial loop exactly.
@@ -361,18 +361,17 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			}
 			uint32_t cur_exit = nonempty ? pos - seg_hi : 0u;
 
-			// ---- phase 2: settle entries in lane order ----
-			bool first_round = true;
+			// ---- phase 2: settle entries ----
+			// Every lane whose counted chain assumed another entry than its neighbour's current
+			// exit repairs itself, all such lanes at once; a repair that never met moves that
+			// lane's exit, so the round repeats until nothing changes.  Lane k is final after at
+			// most k+1 rounds (lane 0's entry is known), usually after the first.
 			for (;;) {
 				uint32_t want = __shfl_up(cur_exit, 1, 64);
 				if (lane == 0) want = cur_entry;
 				const bool need = nonempty && want != cur_entry;
-				const unsigned long long m = __ballot(need);
-				if (m == 0) break;
-				// first round: every lane repairs against its neighbour's speculative exit
-				// in parallel (the common case ends here); afterwards strictly in order.
-				const bool mine = first_round ? need : (lane == (uint32_t)__builtin_ctzll(m));
-				first_round = false;
+				if (__ballot(need) == 0) break;
+				const bool mine = need;
 				uint32_t pa = seg_nom + want;      // true chain  (+)
 				uint32_t pb = seg_nom + cur_entry; // counted chain (-)
 				bool walking = mine && (pa < seg_hi || pb < seg_hi);
