@@ -1,0 +1,76 @@
+"""N > 1 path on CPU: world_size-2 gloo.  Each rank takes its byte-balanced document shard,
+produces the V+5 result vector and all-reduces it exactly as bench.py does over RCCL.  The
+per-rank scorer here is the CPU oracle (test stand-in: the GPU scorer needs a GPU); what is
+under test is the partition and the reduction, against the oracle on the whole corpus."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_ffi as O
+from tokenizer_amd import shard, synth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tokens, corpus, off, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c, o = shard.shard_corpus(corpus, off, rank, world)
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    counts, tt, tb = voc.score(c, o)
+    vec = np.concatenate([counts, np.array([tt, tb], dtype=np.uint64)])
+    t = torch.from_numpy(vec.view(np.int64).copy())
+    shard.all_reduce_counts(t, dist)
+    if rank == 0:
+        q.put(t.numpy().view(np.uint64).copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_tile_the_corpus_and_balance_bytes():
+    corpus, off = synth.wiki_like(3_000_000, seed=4)
+    for world in (1, 2, 3, 8):
+        ranges = [shard.shard_range(off, r, world) for r in range(world)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == len(off) - 1
+        for a, b in zip(ranges, ranges[1:]):
+            assert a[1] == b[0]
+        sizes = [int(off[d1] - off[d0]) for d0, d1 in ranges]
+        assert sum(sizes) == len(corpus)
+        assert max(sizes) - min(sizes) < 300_000  # within one (long) article of each other
+    # degenerate: more ranks than documents
+    tiny = np.array([0, 5, 9], dtype=np.uint64)
+    rs = [shard.shard_range(tiny, r, 4) for r in range(4)]
+    assert rs[0][0] == 0 and rs[-1][1] == 2 and all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_allreduce_equals_single_evaluation():
+    corpus, off = synth.wiki_like(1_500_000, seed=12)
+    tokens = synth.build_vocab(corpus[:400_000], 4000)
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    counts, tt, tb = voc.score(corpus, off)
+    # START/END are per document, so the reduced counts[0:2] must equal the document count
+    expect = np.concatenate([counts, np.array([tt, tb], dtype=np.uint64)])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, tokens, corpus, off, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(got, expect)
