@@ -35,6 +35,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kNoLimit = 0x7FFFFFFFu;
 constexpr uint32_t kLogDepth = 8; // stream entries per lane per log block
+constexpr uint32_t kPendDepth = 8; // first tokens of a lane's speculative chain remembered for the repair
 
 __device__ __forceinline__ void wave_sync() {
 	// LDS is in order per wave; this only stops the compiler moving LDS accesses across.
@@ -205,6 +206,8 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	LaneLog<WIDE> log;
 	log.cells = (LDS_AS typename Q::entry_t *)(wbase + n_vec * 16 + ((bm_words * 4 + 15) & ~15u));
 	log.clear(lane);
+	// ids of the first kPendDepth tokens of every lane's speculative chain, cell (j, lane)
+	LDS_AS typename Q::entry_t *pend = log.cells + 64 * kLogDepth;
 
 	WaveCtx W;
 	W.lds_trie = (const LDS_AS u32x2 *)lds;
@@ -217,7 +220,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 
 	const uint32_t queue = blockIdx.x % kWorkQueues;
 	const uint32_t min_seg = 4 * (((max_len + 4 + 3) / 4) | 1u); // shortest legal lane segment
-	constexpr int kMaxVec = 5; // register prefetch depth: up to 5 x 16 B per lane
+	constexpr int kMaxVec = 7; // register prefetch depth: up to 7 x 16 B per lane
 	const bool reg_prefetch = n_vec <= 64 * kMaxVec;
 
 	for (;;) {
@@ -341,12 +344,24 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			wk.reset(W.root_base);
 			bool active = nonempty && pos < seg_hi;
 			if (has_bounds && active) limit = find_limit(bitmap, pos, stop);
+			// The first kPendDepth tokens that start within 64 bytes of the segment start are
+			// remembered (start bit in `mask`, id in `pend`); `bound` = start of the first token
+			// that is not.  The repair then needs no second walk over this chain.
+			unsigned long long mask = 0;
+			uint32_t nrec = 0;
+			uint32_t bound = pos;
 			while (__ballot(active)) {
 				const bool fin = walk_step(W, wk, active, pos, limit);
 				const uint32_t id = wk.last_len ? wk.last_id : W.unknown_id;
 				const uint32_t len = wk.last_len ? wk.last_len : 1u;
 				if (fin) log.put(lane, id);
+				const uint32_t offp = pos - seg_nom;
+				const bool rec = fin && nrec < kPendDepth && offp < 64;
+				if (rec) pend[nrec * 64 + lane] = (typename Q::entry_t)id;
+				mask |= rec ? (1ull << (offp & 63)) : 0ull;
+				nrec += rec ? 1u : 0u;
 				pos += fin ? len : 0u;
+				bound = rec ? pos : bound;
 				wk.d = fin ? 0u : wk.d;
 				wk.base = fin ? W.root_base : wk.base;
 				wk.last_len = fin ? 0u : wk.last_len;
@@ -366,17 +381,59 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			// exit repairs itself, all such lanes at once; a repair that never met moves that
 			// lane's exit, so the round repeats until nothing changes.  Lane k is final after at
 			// most k+1 rounds (lane 0's entry is known), usually after the first.
-			for (;;) {
+			for (uint32_t round = 0;; round++) {
 				uint32_t want = __shfl_up(cur_exit, 1, 64);
 				if (lane == 0) want = cur_entry;
 				const bool need = nonempty && want != cur_entry;
 				if (__ballot(need) == 0) break;
-				const bool mine = need;
 				uint32_t pa = seg_nom + want;      // true chain  (+)
 				uint32_t pb = seg_nom + cur_entry; // counted chain (-)
-				bool walking = mine && (pa < seg_hi || pb < seg_hi);
-				bool on_a = pa < pb;
 				uint32_t lim2 = kNoLimit;
+				if (round == 0) {
+					// First round: the counted chain is the speculative one (entry 0) whose first
+					// token starts are in `mask`.  Walk only the true chain until it lands on one of
+					// them (or on `bound`): from there on both chains are the same chain.
+					const uint32_t fast_hi = bound < seg_hi ? bound : seg_hi;
+					uint32_t o = pa - seg_nom;
+					bool merged = need && ((o < 64 && ((mask >> (o & 63)) & 1ull)) || pa == bound);
+					bool fw = need && !merged && pa < fast_hi;
+					if (has_bounds && fw) lim2 = find_limit(bitmap, pa, stop);
+					wk.reset(W.root_base);
+					while (__ballot(fw)) {
+						const bool fin = walk_step(W, wk, fw, pa, lim2);
+						const uint32_t id = wk.last_len ? wk.last_id : W.unknown_id;
+						const uint32_t len = wk.last_len ? wk.last_len : 1u;
+						if (fin) log.put(lane, id);
+						pa += fin ? len : 0u;
+						wk.d = fin ? 0u : wk.d;
+						wk.base = fin ? W.root_base : wk.base;
+						wk.last_len = fin ? 0u : wk.last_len;
+						o = pa - seg_nom;
+						const bool hit_b = fin && ((o < 64 && ((mask >> (o & 63)) & 1ull)) || pa == bound);
+						merged = merged || hit_b;
+						fw = fw && !hit_b && pa < fast_hi;
+						if (has_bounds) {
+							const bool cross = fw && pa >= lim2;
+							if (__ballot(cross)) {
+								if (cross) lim2 = find_limit(bitmap, pa, stop);
+							}
+						}
+						log.flush_if_full(Qd, lane);
+					}
+					// take back the speculative tokens that start before the meeting point
+					o = pa - seg_nom;
+					uint32_t rank = nrec;
+					if (merged && pa != bound) rank = (uint32_t)__builtin_popcountll(mask & ((1ull << (o & 63)) - 1ull));
+					if (!need) rank = 0;
+					for (uint32_t jn = 0; __ballot(jn < rank); jn++) {
+						if (jn < rank) log.put(lane, (uint32_t)pend[jn * 64 + lane] | Q::neg);
+						log.flush_if_full(Qd, lane);
+					}
+					// not met yet: the generic dual walk below continues from (pa, bound)
+					pb = merged ? pa : bound;
+				}
+				bool walking = need && pa != pb && (pa < seg_hi || pb < seg_hi);
+				bool on_a = pa < pb;
 				if (has_bounds && walking) lim2 = find_limit(bitmap, on_a ? pa : pb, stop);
 				wk.reset(W.root_base);
 				while (__ballot(walking)) {
@@ -400,7 +457,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 					}
 					log.flush_if_full(Qd, lane);
 				}
-				if (mine) {
+				if (need) {
 					cur_entry = want;
 					if (pa != pb) cur_exit = pa - seg_hi; // never met: the exit moved
 				}
@@ -469,14 +526,17 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) row[i] = bins[i];
 }
 
-// counts[id] += sum over slab rows (int32 partials, sign-extended)
+// counts[id] += sum over slab rows (int32 partials, sign-extended).  grid = (ids / 256, row
+// groups): each thread sums every kReduceGroups-th row and adds its partial with one u64
+// atomic, so the boundary fix-up (which also adds to counts) may run beside this kernel.
+constexpr uint32_t kReduceGroups = 8;
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const uint32_t *slab, uint32_t rows, uint32_t n_ids,
                                                           unsigned long long *counts) {
 	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
 	if (id >= n_ids) return;
 	long long sum = 0;
-	for (uint32_t r = 0; r < rows; r++) sum += (long long)(int32_t)slab[(size_t)r * n_ids + id];
-	counts[id] += (unsigned long long)sum;
+	for (uint32_t r = blockIdx.y; r < rows; r += kReduceGroups) sum += (long long)(int32_t)slab[(size_t)r * n_ids + id];
+	if (sum != 0) atomicAdd(&counts[id], (unsigned long long)sum);
 }
 
 } // namespace
@@ -486,9 +546,9 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const uint32_t *slab, 
 uint32_t stream_block_bytes(uint32_t wide_ids) { return 64 * kLogDepth * (wide_ids ? 4 : 2); }
 
 bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num_cus, TileScanPlan *plan) {
-	static const uint32_t kSeg[] = {68, 132, 260, 516, 1028};
+	static const uint32_t kSeg[] = {36, 52, 68, 100, 132, 196, 260, 516, 1028};
 	uint32_t seg = 0;
-	uint32_t want_seg = 68;
+	uint32_t want_seg = 100;
 	if (const char *s = getenv("TOKSCORE_SEG")) want_seg = (uint32_t)atoi(s);
 	for (uint32_t s : kSeg) {
 		if (s >= max_len + 4 && s >= want_seg) {
@@ -509,12 +569,15 @@ bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num
 		const uint32_t tile_cap = 64 * seg + halo + 16;
 		const uint32_t n_vec = (tile_cap + 15) / 16;
 		const uint32_t bm_words = (tile_cap + 31) / 32 + 1;
-		wave_bytes = n_vec * 16 + ((bm_words * 4 + 15) & ~15u) + stream_block_bytes(wide);
+		wave_bytes = n_vec * 16 + ((bm_words * 4 + 15) & ~15u) + stream_block_bytes(wide) + 64 * kPendDepth * (wide ? 4 : 2);
 		if ((uint64_t)wave_bytes * waves + 8 * 1024 <= lds_total) break;
 		if (waves == 1) return false;
 		waves >>= 1; // long segments: fewer waves so that the tiles still fit
 	}
-	uint32_t lds_slots = (lds_total - wave_bytes * waves) / 8;
+	uint32_t lds_budget = lds_total;
+	if (const char *s = getenv("TOKSCORE_BLOCKS_PER_CU")) lds_budget = lds_total / std::max(1, atoi(s)) - 512;
+	if (wave_bytes * waves + 64 > lds_budget) return false;
+	uint32_t lds_slots = (lds_budget - wave_bytes * waves) / 8;
 	if (const char *s = getenv("TOKSCORE_LDS_SLOTS")) lds_slots = std::min<uint32_t>(lds_slots, (uint32_t)atoi(s));
 	if (lds_slots > T.nslots) lds_slots = T.nslots;
 	if (lds_slots < 1) lds_slots = 1;
@@ -522,7 +585,9 @@ bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num
 	plan->seg_bytes = seg;
 	plan->lds_slots = lds_slots;
 	plan->lds_bytes = lds_slots * 8 + wave_bytes * waves;
-	plan->blocks = num_cus;
+	uint32_t per_cu = 1;
+	if (const char *s = getenv("TOKSCORE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(s));
+	plan->blocks = num_cus * per_cu;
 	plan->wide_ids = wide;
 	return true;
 }
@@ -565,8 +630,8 @@ void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, 
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		hipLaunchKernelGGL(hist_kernel<false>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab);
 	}
-	hipLaunchKernelGGL(slab_reduce_kernel, dim3((n_ids + 255) / 256), dim3(256), 0, stream, slab, slab_blocks, n_ids,
-	                   counts);
+	hipLaunchKernelGGL(slab_reduce_kernel, dim3((n_ids + 255) / 256, kReduceGroups), dim3(256), 0, stream, slab,
+	                   slab_blocks, n_ids, counts);
 }
 
 } // namespace tokscore

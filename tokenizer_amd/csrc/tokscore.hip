@@ -36,6 +36,8 @@ struct tokscore_ctx {
 	int device = -1;
 	int num_cus = 256;
 	hipStream_t stream = nullptr;
+	hipStream_t side = nullptr;      // boundary fix-up runs here, beside the histogram
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	// ring of event sets, one per score call, so a caller can time many calls back to back and
 	// read the kernel durations afterwards without a host sync inside its timed region
 	static constexpr int kRing = 256;
@@ -118,6 +120,9 @@ void free_corpus(tokscore_ctx *c) {
 }
 
 void free_plan(tokscore_ctx *c) {
+	// nothing enqueued by an earlier asynchronous evaluation may still use these buffers
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
+	if (c->side) (void)hipStreamSynchronize(c->side);
 	if (c->d_chunk_begin) (void)hipFree(c->d_chunk_begin);
 	if (c->d_chunk_state) (void)hipFree(c->d_chunk_state);
 	if (c->d_chunk_first_doc) (void)hipFree(c->d_chunk_first_doc);
@@ -285,9 +290,15 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		HIP_TRY(c, hipEventRecord(c->ev[1], s));
 		launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s);
 		HIP_TRY(c, hipEventRecord(c->ev[2], s));
-		launch_fixup(T, C, S, d_out, s);
+		// the chunk-boundary fix-up (a few serial walks, latency bound) and the histogram of the
+		// token stream only share d_out, which both update with atomics: run them side by side
+		HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+		HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+		launch_fixup(T, C, S, d_out, c->side);
+		HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
 		HIP_TRY(c, hipEventRecord(c->ev[3], s));
 		launch_histogram(Q, c->tile, (uint32_t)c->V, d_out, c->d_slab, c->slab_blocks, s);
+		HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
 	} else {
 		HIP_TRY(c, hipEventRecord(c->ev[1], s));
 		launch_scan_generic(T, C, S, d_out, s);
@@ -352,6 +363,12 @@ int tokscore_create(tokscore_ctx **out, int device) {
 		delete c;
 		return TOKSCORE_E_HIP;
 	}
+	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+	    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+		delete c;
+		return TOKSCORE_E_HIP;
+	}
 	for (auto &set : c->ring) {
 		for (auto &e : set) {
 			if (hipEventCreate(&e) != hipSuccess) {
@@ -377,6 +394,7 @@ void tokscore_destroy(tokscore_ctx *c) {
 	if (!c->hostonly) {
 		(void)hipSetDevice(c->device);
 		(void)hipStreamSynchronize(c->stream);
+		if (c->side) (void)hipStreamSynchronize(c->side);
 		free_plan(c);
 		free_corpus(c);
 		if (c->d_slots) (void)hipFree(c->d_slots);
@@ -384,6 +402,9 @@ void tokscore_destroy(tokscore_ctx *c) {
 		for (auto &set : c->ring)
 			for (auto &e : set)
 				if (e) (void)hipEventDestroy(e);
+		if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+		if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+		if (c->side) (void)hipStreamDestroy(c->side);
 		if (c->stream) (void)hipStreamDestroy(c->stream);
 	}
 	delete c;
