@@ -34,6 +34,11 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kNoLimit = 0x7FFFFFFFu;
+
+// LDS pointers are 32-bit byte addresses; the walk keeps its positions as such addresses so
+// that a byte read needs no address arithmetic.
+__device__ __forceinline__ uint32_t lds_addr(const LDS_AS void *p) { return (uint32_t)(uintptr_t)p; }
+template <class T> __device__ __forceinline__ LDS_AS T *lds_ptr(uint32_t a) { return (LDS_AS T *)(uintptr_t)a; }
 constexpr uint32_t kLogDepth = 8; // stream entries per lane per log block
 constexpr uint32_t kPendDepth = 8; // first tokens of a lane's speculative chain remembered for the repair
 
@@ -84,18 +89,25 @@ __device__ __forceinline__ uint32_t find_limit(const LDS_AS uint32_t *bm, uint32
 // a histogram), null cells included.
 template <bool WIDE> struct LaneLog {
 	using Q = QTraits<WIDE>;
+	static constexpr uint32_t kRowBytes = 64 * sizeof(typename Q::entry_t);
 	LDS_AS typename Q::entry_t *cells;
-	uint32_t k; // per lane: cells used in this lane's column
+	uint32_t ka;   // per lane: LDS address of the next free cell of this lane's column
+	uint32_t kend; // per lane: LDS address one past the column
 
+	__device__ __forceinline__ void init(LDS_AS typename Q::entry_t *c, uint32_t lane) {
+		cells = c;
+		kend = lds_addr(c + lane) + kLogDepth * kRowBytes;
+		clear(lane);
+	}
 	__device__ __forceinline__ void clear(uint32_t lane) {
 		constexpr uint32_t words = 64 * kLogDepth * sizeof(typename Q::entry_t) / 4;
 		LDS_AS uint32_t *w = (LDS_AS uint32_t *)cells;
 		for (uint32_t i = lane; i < words; i += 64) w[i] = Q::null_word;
-		k = 0;
+		ka = kend - kLogDepth * kRowBytes;
 	}
-	__device__ __forceinline__ void put(uint32_t lane, uint32_t val) {
-		cells[k * 64 + lane] = (typename Q::entry_t)val;
-		k++;
+	__device__ __forceinline__ void put(uint32_t val) {
+		*lds_ptr<typename Q::entry_t>(ka) = (typename Q::entry_t)val;
+		ka += kRowBytes;
 	}
 	// Stream space is handed out in batches of kStreamBatch blocks, so the single
 	// allocation word sees one atomic per batch, not per block (one word sustains only
@@ -126,10 +138,10 @@ template <bool WIDE> struct LaneLog {
 		wave_sync();
 	}
 	__device__ __forceinline__ void flush_if_full(const StreamDev &S, uint32_t lane) {
-		if (__ballot(k >= kLogDepth)) flush(S, lane);
+		if (__builtin_amdgcn_ballot_w64(ka >= kend)) flush(S, lane);
 	}
 	__device__ __forceinline__ void finish(const StreamDev &S, uint32_t lane) {
-		if (__ballot(k != 0)) flush(S, lane);
+		if (__builtin_amdgcn_ballot_w64(ka != kend - kLogDepth * kRowBytes)) flush(S, lane);
 		if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = used;
 	}
 };
@@ -144,37 +156,40 @@ struct WaveCtx {
 	uint32_t unknown_id;
 };
 
-// One greedy chain walker (per lane): the token in progress started at `pos`.
+// One greedy chain walker (per lane).  Positions are LDS byte addresses inside the tile.
 struct Walker {
-	uint32_t base, d, last_len, last_id;
-	__device__ __forceinline__ void reset(uint32_t root_base) {
-		base = root_base;
-		d = 0;
-		last_len = 0;
-		last_id = 0;
+	uint32_t cp;   // address of the next byte to look up (token start + depth)
+	uint32_t nb;   // base of the current trie node
+	uint32_t lend; // address just past the best token so far (start + 1 while there is none)
+	uint32_t lid;  // its id (UNKNOWN while there is none, SolutionFile.cpp:92-94)
+	__device__ __forceinline__ void start(uint32_t at, uint32_t root_base, uint32_t unknown_id) {
+		cp = at;
+		nb = root_base;
+		lend = at + 1;
+		lid = unknown_id;
 	}
 };
 
-// One trie lookup for the token that started at pos, written without divergent branches
-// (the kernel is instruction-issue bound: every exec-mask round trip costs).  Every lane
-// executes it; `on` = this lane has a token in progress.  Returns true when the token is
-// complete (miss, window clipped at `limit`, or a leaf was reached); then w.last_len /
-// w.last_id describe it (last_len == 0: UNKNOWN, SolutionFile.cpp:92-94).
-__device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, bool on, uint32_t pos, uint32_t limit) {
-	const uint32_t q = pos + w.d; // < tile_cap for every lane, finished ones included
-	const uint32_t c = W.tile[q];
-	const uint32_t t = w.base + c;
-	const uint32_t tl = t < W.lds_slots ? t : 0u;
-	u32x2 e = W.lds_trie[tl];
-	if (t >= W.lds_slots) e = W.g_trie[t]; // cold slot: L2 (t < nslots: base + 255 is always in range)
-	const bool hit = on && q < limit && (e.x & kSlotKeyMask) == (c | kSlotValid);
-	const uint32_t nbase = e.x >> kSlotBaseShift;
-	w.d += hit ? 1u : 0u;
-	w.base = hit ? nbase : w.base;
+// One trie lookup of the token in progress.  Returns true when the token is complete (miss,
+// window clipped at `lim`, or a leaf was reached): then it is [start, w.cp) with id w.lid,
+// w.cp is the next token's start and w.nb is the root again; the caller re-arms w.lend /
+// w.lid.
+__device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t lim) {
+	const uint32_t c = *lds_ptr<const uint8_t>(w.cp);
+	const uint32_t t = w.nb + c;
+	const bool cold = t >= W.lds_slots;
+	u32x2 e = W.lds_trie[cold ? 0u : t];
+	if (cold) e = W.g_trie[t]; // cold slot: L2 (t < nslots: base + 255 is always in range)
+	const bool hit = (e.x & kSlotKeyMask) == (c | kSlotValid) && w.cp < lim;
+	const uint32_t cp1 = w.cp + 1;
 	const bool term = hit && e.y != 0;
-	w.last_len = term ? w.d : w.last_len;
-	w.last_id = term ? e.y : w.last_id;
-	return on && !(hit && nbase != 0); // a leaf ends the token without another lookup
+	w.lend = term ? cp1 : w.lend;
+	w.lid = term ? e.y : w.lid;
+	const uint32_t nbase = e.x >> kSlotBaseShift;
+	const bool cont = hit && nbase != 0; // a leaf ends the token without another lookup
+	w.cp = cont ? cp1 : w.lend;
+	w.nb = cont ? nbase : W.root_base;
+	return !cont;
 }
 
 template <bool WIDE>
@@ -204,10 +219,11 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	LDS_AS unsigned char *tile = wbase;
 	LDS_AS uint32_t *bitmap = (LDS_AS uint32_t *)(wbase + n_vec * 16);
 	LaneLog<WIDE> log;
-	log.cells = (LDS_AS typename Q::entry_t *)(wbase + n_vec * 16 + ((bm_words * 4 + 15) & ~15u));
-	log.clear(lane);
+	log.init((LDS_AS typename Q::entry_t *)(wbase + n_vec * 16 + ((bm_words * 4 + 15) & ~15u)), lane);
 	// ids of the first kPendDepth tokens of every lane's speculative chain, cell (j, lane)
-	LDS_AS typename Q::entry_t *pend = log.cells + 64 * kLogDepth;
+	const uint32_t pend_a = lds_addr(log.cells + 64 * kLogDepth + lane);
+	constexpr uint32_t kRow = LaneLog<WIDE>::kRowBytes;
+	const uint32_t tile_a = lds_addr(tile);
 
 	WaveCtx W;
 	W.lds_trie = (const LDS_AS u32x2 *)lds;
@@ -337,44 +353,50 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			const bool nonempty = seg_lo < seg_hi;
 			if (!nonempty) seg_hi = seg_lo;
 			const uint32_t stop = seg_hi + max_len; // no walk of this segment reads at/after stop
+			const uint32_t seg_a = tile_a + seg_nom;  // LDS addresses from here on
+			const uint32_t hi_a = tile_a + seg_hi;
 			uint32_t cur_entry = (lane == 0) ? carry : 0u;
-			uint32_t pos = seg_lo + ((lane == 0) ? carry : 0u);
-			uint32_t limit = kNoLimit;
 			Walker wk;
-			wk.reset(W.root_base);
-			bool active = nonempty && pos < seg_hi;
-			if (has_bounds && active) limit = find_limit(bitmap, pos, stop);
-			// The first kPendDepth tokens that start within 64 bytes of the segment start are
-			// remembered (start bit in `mask`, id in `pend`); `bound` = start of the first token
-			// that is not.  The repair then needs no second walk over this chain.
-			unsigned long long mask = 0;
-			uint32_t nrec = 0;
-			uint32_t bound = pos;
-			while (__ballot(active)) {
-				const bool fin = walk_step(W, wk, active, pos, limit);
-				const uint32_t id = wk.last_len ? wk.last_id : W.unknown_id;
-				const uint32_t len = wk.last_len ? wk.last_len : 1u;
-				if (fin) log.put(lane, id);
-				const uint32_t offp = pos - seg_nom;
-				const bool rec = fin && nrec < kPendDepth && offp < 64;
-				if (rec) pend[nrec * 64 + lane] = (typename Q::entry_t)id;
-				mask |= rec ? (1ull << (offp & 63)) : 0ull;
-				nrec += rec ? 1u : 0u;
-				pos += fin ? len : 0u;
-				bound = rec ? pos : bound;
-				wk.d = fin ? 0u : wk.d;
-				wk.base = fin ? W.root_base : wk.base;
-				wk.last_len = fin ? 0u : wk.last_len;
-				active = pos < seg_hi;
-				if (has_bounds) {
-					const bool cross = active && pos >= limit;
-					if (__ballot(cross)) {
-						if (cross) limit = find_limit(bitmap, pos, stop);
+			wk.start(tile_a + seg_lo + cur_entry, W.root_base, W.unknown_id);
+			uint32_t lim_a = kNoLimit;
+			bool active = nonempty && wk.cp < hi_a;
+			if (has_bounds && active) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
+			// The ends of the chain's first tokens (at most kPendDepth, within 32 bytes of the
+			// segment start) are remembered: end bit in `mask`, id in the lane's pend column;
+			// `bound` = the last such end.  The repair then needs no second walk over them.
+			uint32_t mask = 0;
+			uint32_t pa_w = pend_a;
+			uint32_t bound = wk.cp;
+			// The hot loop holds nothing but the walk; it is left whenever a log column is full
+			// or a lane's next token starts past its document limit, both handled out here
+			// (wk.lend > wk.cp tells a lane at a token start from one in the middle of a token,
+			// whose cp may legitimately have reached its limit).
+			for (;;) {
+				bool stall;
+				do {
+					stall = false;
+					if (active) {
+						if (walk_step(W, wk, lim_a)) {
+							log.put(wk.lid);
+							const uint32_t o = wk.cp - seg_a;
+							if (o < 32 && pa_w < pend_a + kPendDepth * kRow) {
+								*lds_ptr<typename Q::entry_t>(pa_w) = (typename Q::entry_t)wk.lid;
+								pa_w += kRow;
+								mask |= 1u << o;
+								bound = wk.cp;
+							}
+							wk.lend = wk.cp + 1;
+							wk.lid = W.unknown_id;
+							active = wk.cp < hi_a;
+							stall = log.ka >= log.kend || (active && wk.cp >= lim_a);
+						}
 					}
-				}
+				} while (__builtin_amdgcn_ballot_w64(stall) == 0 && __builtin_amdgcn_ballot_w64(active) != 0);
 				log.flush_if_full(Qd, lane);
+				if (has_bounds && active && wk.lend > wk.cp && wk.cp >= lim_a) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
+				if (__builtin_amdgcn_ballot_w64(active) == 0) break;
 			}
-			uint32_t cur_exit = nonempty ? pos - seg_hi : 0u;
+			uint32_t cur_exit = nonempty ? wk.cp - hi_a : 0u;
 
 			// ---- phase 2: settle entries ----
 			// Every lane whose counted chain assumed another entry than its neighbour's current
@@ -385,81 +407,82 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				uint32_t want = __shfl_up(cur_exit, 1, 64);
 				if (lane == 0) want = cur_entry;
 				const bool need = nonempty && want != cur_entry;
-				if (__ballot(need) == 0) break;
-				uint32_t pa = seg_nom + want;      // true chain  (+)
-				uint32_t pb = seg_nom + cur_entry; // counted chain (-)
-				uint32_t lim2 = kNoLimit;
+				if (__builtin_amdgcn_ballot_w64(need) == 0) break;
+				uint32_t pa = seg_a + want;      // true chain  (+)
+				uint32_t pb = seg_a + cur_entry; // counted chain (-)
 				if (round == 0) {
 					// First round: the counted chain is the speculative one (entry 0) whose first
-					// token starts are in `mask`.  Walk only the true chain until it lands on one of
-					// them (or on `bound`): from there on both chains are the same chain.
-					const uint32_t fast_hi = bound < seg_hi ? bound : seg_hi;
-					uint32_t o = pa - seg_nom;
-					bool merged = need && ((o < 64 && ((mask >> (o & 63)) & 1ull)) || pa == bound);
+					// token ends are in `mask`.  Walk only the true chain until it lands on one of
+					// them: from there on both chains are the same chain.
+					const uint32_t fast_hi = bound < hi_a ? bound : hi_a;
+					bool merged = need && want < 32 && ((mask >> want) & 1u);
 					bool fw = need && !merged && pa < fast_hi;
-					if (has_bounds && fw) lim2 = find_limit(bitmap, pa, stop);
-					wk.reset(W.root_base);
-					while (__ballot(fw)) {
-						const bool fin = walk_step(W, wk, fw, pa, lim2);
-						const uint32_t id = wk.last_len ? wk.last_id : W.unknown_id;
-						const uint32_t len = wk.last_len ? wk.last_len : 1u;
-						if (fin) log.put(lane, id);
-						pa += fin ? len : 0u;
-						wk.d = fin ? 0u : wk.d;
-						wk.base = fin ? W.root_base : wk.base;
-						wk.last_len = fin ? 0u : wk.last_len;
-						o = pa - seg_nom;
-						const bool hit_b = fin && ((o < 64 && ((mask >> (o & 63)) & 1ull)) || pa == bound);
-						merged = merged || hit_b;
-						fw = fw && !hit_b && pa < fast_hi;
-						if (has_bounds) {
-							const bool cross = fw && pa >= lim2;
-							if (__ballot(cross)) {
-								if (cross) lim2 = find_limit(bitmap, pa, stop);
+					wk.start(pa, W.root_base, W.unknown_id);
+					lim_a = kNoLimit;
+					if (has_bounds && fw) lim_a = tile_a + find_limit(bitmap, pa - tile_a, stop);
+					for (;;) {
+						bool stall;
+						do {
+							stall = false;
+							if (fw) {
+								if (walk_step(W, wk, lim_a)) {
+									log.put(wk.lid);
+									const uint32_t o = wk.cp - seg_a;
+									const bool hit_b = o < 32 && ((mask >> o) & 1u);
+									merged = merged || hit_b;
+									fw = !hit_b && wk.cp < fast_hi;
+									wk.lend = wk.cp + 1;
+									wk.lid = W.unknown_id;
+									stall = log.ka >= log.kend || (fw && wk.cp >= lim_a);
+								}
 							}
-						}
+						} while (__builtin_amdgcn_ballot_w64(stall) == 0 && __builtin_amdgcn_ballot_w64(fw) != 0);
 						log.flush_if_full(Qd, lane);
+						if (has_bounds && fw && wk.lend > wk.cp && wk.cp >= lim_a) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
+						if (__builtin_amdgcn_ballot_w64(fw) == 0) break;
 					}
-					// take back the speculative tokens that start before the meeting point
-					o = pa - seg_nom;
-					uint32_t rank = nrec;
-					if (merged && pa != bound) rank = (uint32_t)__builtin_popcountll(mask & ((1ull << (o & 63)) - 1ull));
-					if (!need) rank = 0;
-					for (uint32_t jn = 0; __ballot(jn < rank); jn++) {
-						if (jn < rank) log.put(lane, (uint32_t)pend[jn * 64 + lane] | Q::neg);
+					pa = wk.cp;
+					// take back the speculative tokens that end at or before the meeting point
+					uint32_t taken = mask;
+					if (merged) taken &= (2u << ((pa - seg_a) & 31)) - 1u;
+					const uint32_t rank = need ? (uint32_t)__builtin_popcount(taken) : 0u;
+					for (uint32_t jn = 0; __builtin_amdgcn_ballot_w64(jn < rank); jn++) {
+						if (jn < rank) log.put((uint32_t)*lds_ptr<typename Q::entry_t>(pend_a + jn * kRow) | Q::neg);
 						log.flush_if_full(Qd, lane);
 					}
 					// not met yet: the generic dual walk below continues from (pa, bound)
 					pb = merged ? pa : bound;
 				}
-				bool walking = need && pa != pb && (pa < seg_hi || pb < seg_hi);
+				bool walking = need && pa != pb && (pa < hi_a || pb < hi_a);
 				bool on_a = pa < pb;
-				if (has_bounds && walking) lim2 = find_limit(bitmap, on_a ? pa : pb, stop);
-				wk.reset(W.root_base);
-				while (__ballot(walking)) {
-					const bool fin = walk_step(W, wk, walking, on_a ? pa : pb, lim2);
-					const uint32_t id = wk.last_len ? wk.last_id : W.unknown_id;
-					const uint32_t len = wk.last_len ? wk.last_len : 1u;
-					if (fin) log.put(lane, on_a ? id : (id | Q::neg));
-					pa += (fin && on_a) ? len : 0u;
-					pb += (fin && !on_a) ? len : 0u;
-					wk.d = fin ? 0u : wk.d;
-					wk.base = fin ? W.root_base : wk.base;
-					wk.last_len = fin ? 0u : wk.last_len;
-					walking = walking && pa != pb && (pa < seg_hi || pb < seg_hi);
-					on_a = pa < pb;
-					if (has_bounds) {
-						const uint32_t p = on_a ? pa : pb;
-						const bool cross = walking && p >= lim2;
-						if (__ballot(cross)) {
-							if (cross) lim2 = find_limit(bitmap, p, stop);
+				wk.start(on_a ? pa : pb, W.root_base, W.unknown_id);
+				lim_a = kNoLimit;
+				if (has_bounds && walking) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
+				for (;;) {
+					bool stall;
+					do {
+						stall = false;
+						if (walking) {
+							if (walk_step(W, wk, lim_a)) {
+								log.put(on_a ? wk.lid : (wk.lid | Q::neg));
+								pa = on_a ? wk.cp : pa;
+								pb = on_a ? pb : wk.cp;
+								walking = pa != pb && (pa < hi_a || pb < hi_a);
+								on_a = pa < pb;
+								wk.cp = on_a ? pa : pb;
+								wk.lend = wk.cp + 1;
+								wk.lid = W.unknown_id;
+								stall = log.ka >= log.kend || (walking && wk.cp >= lim_a);
+							}
 						}
-					}
+					} while (__builtin_amdgcn_ballot_w64(stall) == 0 && __builtin_amdgcn_ballot_w64(walking) != 0);
 					log.flush_if_full(Qd, lane);
+					if (has_bounds && walking && wk.lend > wk.cp && wk.cp >= lim_a) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
+					if (__builtin_amdgcn_ballot_w64(walking) == 0) break;
 				}
 				if (need) {
 					cur_entry = want;
-					if (pa != pb) cur_exit = pa - seg_hi; // never met: the exit moved
+					if (pa != pb) cur_exit = pa - hi_a; // never met: the exit moved
 				}
 			}
 

@@ -28,7 +28,7 @@ def main():
     for extra in sys.argv[2:]:
         configs.append(dict(kv.split("=") for kv in extra.split(",")))
     for cfg in configs:
-        for k in ("TOKSCORE_SEG", "TOKSCORE_WAVES", "TOKSCORE_LDS_SLOTS", "TOKSCORE_CHUNK", "TOKSCORE_SCAN", "TOKSCORE_BLOCKS_PER_CU"):
+        for k in ("TOKSCORE_SEG", "TOKSCORE_WAVES", "TOKSCORE_LDS_SLOTS", "TOKSCORE_CHUNK", "TOKSCORE_SCAN", "TOKSCORE_BLOCKS_PER_CU", "TOKSCORE_PARK"):
             os.environ.pop(k, None)
         os.environ.update(cfg)
         s = ta.Scorer(0)
