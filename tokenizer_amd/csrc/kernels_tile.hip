@@ -35,6 +35,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr uint32_t kNoLimit = 0x7FFFFFFFu;
 
+// A wave-uniform 64-bit value (a lane mask) that the compiler does not recognise as such.
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long x) {
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+	const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+	return ((unsigned long long)hi << 32) | lo;
+}
+
 // LDS pointers are 32-bit byte addresses; the walk keeps its positions as such addresses so
 // that a byte read needs no address arithmetic.
 __device__ __forceinline__ uint32_t lds_addr(const LDS_AS void *p) { return (uint32_t)(uintptr_t)p; }
@@ -192,6 +199,135 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	return !cont;
 }
 
+// ---- the two hot loops, written in gfx950 assembly --------------------------------------
+// The scan is bound by instruction issue (a SIMD issues about one instruction per four
+// cycles over all of its waves), so what counts is the number of instructions per trie
+// lookup, scalar ones included.  The compiler's code for the loops below (kept in C++ for the
+// rarely taken dual walk) needs about 100 per lookup; these need about 50.
+// Conventions: exec = lanes still walking; v24-v27, s[38:43] are scratch; a lane's state is
+// the Walker (cp, nb, lend, lid); the loop is left when no lane walks any more or when
+// `stall` is non-zero (a log column is full, or a lane's next token starts at or after its
+// document limit), which the C++ around it handles before it re-enters.
+//
+// One trie lookup for the lanes in %[act]: afterwards vcc = lanes whose token goes on
+// (cp and nb already advanced), s[42:43] = lanes whose token is complete, scc = any such.
+#define TOK_ASM_LOOKUP(TAG)                                                            \
+	"s_mov_b64 exec, %[act]\n"                                                         \
+	"ds_read_u8 v24, %[cp]\n"                                                          \
+	"s_waitcnt lgkmcnt(0)\n"                                                           \
+	"v_add_lshl_u32 v25, %[nb], v24, 3\n"      /* byte offset of slot nb + c        */ \
+	"v_cmp_gt_u32 vcc, %[ldsb], v25\n"         /* slot staged in LDS?               */ \
+	"s_andn2_b64 s[40:41], exec, vcc\n"                                                \
+	"s_mov_b64 exec, vcc\n"                                                            \
+	"ds_read_b64 v[26:27], v25\n"                                                      \
+	"s_cbranch_scc0 .Lhot" TAG "%=\n"                                                  \
+	"s_mov_b64 exec, s[40:41]\n"                                                       \
+	"global_load_dwordx2 v[26:27], v25, %[trie]\n" /* cold slot: L2                 */ \
+	".Lhot" TAG "%=:\n"                                                                \
+	"s_mov_b64 exec, %[act]\n"                                                         \
+	"s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                  \
+	"v_and_b32 v25, 0x1ff, v26\n"                                                      \
+	"v_or_b32 v24, 0x100, v24\n"                                                       \
+	"v_cmp_eq_u32 vcc, v25, v24\n"             /* label matches and slot valid      */ \
+	"v_cmp_lt_u32 s[40:41], %[cp], %[lim]\n"   /* byte inside the document          */ \
+	"s_and_b64 s[40:41], s[40:41], vcc\n"      /* hit                               */ \
+	"v_add_u32 %[cp], 1, %[cp]\n"                                                      \
+	"v_cmp_ne_u32 vcc, 0, v27\n"                                                       \
+	"s_and_b64 vcc, vcc, s[40:41]\n"           /* hit on a token end                */ \
+	"v_cndmask_b32 %[lend], %[lend], %[cp], vcc\n"                                     \
+	"v_cndmask_b32 %[lid], %[lid], v27, vcc\n"                                         \
+	"v_lshrrev_b32 %[nb], 9, v26\n"                                                    \
+	"v_cmp_ne_u32 vcc, 0, %[nb]\n"                                                     \
+	"s_and_b64 vcc, vcc, s[40:41]\n"           /* hit on a node with children       */ \
+	"s_andn2_b64 s[42:43], exec, vcc\n"        /* token complete                    */
+
+// Phase 1 (speculative chain): log the id, remember the token's end while it lies within 32
+// bytes of the segment start, re-arm the walker, retire the lane at its segment end.
+#define TOK_ASM_PHASE1(DSW, ROW)                                                       \
+	asm volatile("s_mov_b64 s[38:39], exec\n"                                          \
+	             "s_mov_b64 %[act], %[actin]\n"                                          \
+	             ".Ltop%=:\n" TOK_ASM_LOOKUP("a")                                      \
+	             "s_cbranch_scc0 .Ltop%=\n"                                            \
+	             "s_mov_b64 exec, s[42:43]\n"                                          \
+	             "v_mov_b32 %[cp], %[lend]\n"                                          \
+	             "v_mov_b32 %[nb], %[root]\n"                                          \
+	             DSW " %[ka], %[lid]\n"                                                \
+	             "v_add_u32 %[ka], " ROW ", %[ka]\n"                                   \
+	             "v_sub_u32 v24, %[cp], %[seg]\n"                                      \
+	             "v_cmp_gt_u32 vcc, 32, v24\n"                                         \
+	             "v_cmp_lt_u32 s[40:41], %[pw], %[pwend]\n"                            \
+	             "s_and_b64 vcc, vcc, s[40:41]\n"                                      \
+	             "s_and_b64 exec, exec, vcc\n"                                         \
+	             DSW " %[pw], %[lid]\n"                                                \
+	             "v_add_u32 %[pw], " ROW ", %[pw]\n"                                   \
+	             "v_lshl_or_b32 %[mask], 1, v24, %[mask]\n"                            \
+	             "s_mov_b64 exec, s[42:43]\n"                                          \
+	             "v_add_u32 %[lend], 1, %[cp]\n"                                       \
+	             "v_mov_b32 %[lid], %[unk]\n"                                          \
+	             "v_cmp_ge_u32 vcc, %[cp], %[hi]\n"                                    \
+	             "s_andn2_b64 %[act], %[act], vcc\n"                                   \
+	             "v_cmp_ge_u32 vcc, %[ka], %[kend]\n"                                  \
+	             "v_cmp_ge_u32 s[40:41], %[cp], %[lim]\n"                              \
+	             "s_and_b64 s[40:41], s[40:41], %[act]\n"                              \
+	             "s_or_b64 %[stall], vcc, s[40:41]\n"                                  \
+	             "s_cmp_lg_u64 %[stall], 0\n"                                          \
+	             "s_cbranch_scc1 .Lout%=\n"                                            \
+	             "s_cmp_lg_u64 %[act], 0\n"                                            \
+	             "s_cbranch_scc1 .Ltop%=\n"                                            \
+	             ".Lout%=:\n"                                                          \
+	             "s_mov_b64 exec, s[38:39]\n"                                          \
+	             : [cp] "+v"(wk.cp), [nb] "+v"(wk.nb), [lend] "+v"(wk.lend), [lid] "+v"(wk.lid),   \
+	               [ka] "+v"(log.ka), [pw] "+v"(pa_w), [mask] "+v"(mask), [act] "=&s"(act_out),    \
+	               [stall] "=&s"(stall)                                                            \
+	             : [lim] "v"(lim_a), [hi] "v"(hi_a), [kend] "v"(log.kend), [seg] "v"(seg_a),       \
+	               [pwend] "v"(pend_end), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes), [trie] "s"(W.g_trie),        \
+	               [unk] "s"(W.unknown_id), [root] "s"(W.root_base)                                \
+	             : "v24", "v25", "v26", "v27", "s38", "s39", "s40", "s41", "s42", "s43", "vcc",    \
+	               "scc", "memory")
+
+// Phase 2, first round (true chain of a lane whose entry guess was wrong): log the id, stop
+// at the first token end that the speculative chain also had (`mask`) or at `fasthi`.
+#define TOK_ASM_REPAIR(DSW, ROW)                                                       \
+	asm volatile("s_mov_b64 s[38:39], exec\n"                                          \
+	             "s_mov_b64 %[act], %[actin]\n"                                          \
+	             ".Ltop%=:\n" TOK_ASM_LOOKUP("b")                                      \
+	             "s_cbranch_scc0 .Ltop%=\n"                                            \
+	             "s_mov_b64 exec, s[42:43]\n"                                          \
+	             "v_mov_b32 %[cp], %[lend]\n"                                          \
+	             "v_mov_b32 %[nb], %[root]\n"                                          \
+	             DSW " %[ka], %[lid]\n"                                                \
+	             "v_add_u32 %[ka], " ROW ", %[ka]\n"                                   \
+	             "v_sub_u32 v24, %[cp], %[seg]\n"                                      \
+	             "v_lshrrev_b32 v25, v24, %[mask]\n"                                   \
+	             "v_and_b32 v25, 1, v25\n"                                             \
+	             "v_cmp_gt_u32 vcc, 32, v24\n"                                         \
+	             "v_cmp_eq_u32 s[40:41], 1, v25\n"                                     \
+	             "s_and_b64 s[40:41], s[40:41], vcc\n"      /* met the counted chain */ \
+	             "s_or_b64 %[merged], %[merged], s[40:41]\n"                           \
+	             "v_cmp_lt_u32 vcc, %[cp], %[fasthi]\n"                                \
+	             "s_andn2_b64 vcc, vcc, s[40:41]\n"         /* goes on               */ \
+	             "s_andn2_b64 %[act], %[act], s[42:43]\n"                              \
+	             "s_or_b64 %[act], %[act], vcc\n"                                      \
+	             "v_add_u32 %[lend], 1, %[cp]\n"                                       \
+	             "v_mov_b32 %[lid], %[unk]\n"                                          \
+	             "v_cmp_ge_u32 vcc, %[ka], %[kend]\n"                                  \
+	             "v_cmp_ge_u32 s[40:41], %[cp], %[lim]\n"                              \
+	             "s_and_b64 s[40:41], s[40:41], %[act]\n"                              \
+	             "s_or_b64 %[stall], vcc, s[40:41]\n"                                  \
+	             "s_cmp_lg_u64 %[stall], 0\n"                                          \
+	             "s_cbranch_scc1 .Lout%=\n"                                            \
+	             "s_cmp_lg_u64 %[act], 0\n"                                            \
+	             "s_cbranch_scc1 .Ltop%=\n"                                            \
+	             ".Lout%=:\n"                                                          \
+	             "s_mov_b64 exec, s[38:39]\n"                                          \
+	             : [cp] "+v"(wk.cp), [nb] "+v"(wk.nb), [lend] "+v"(wk.lend), [lid] "+v"(wk.lid),   \
+	               [ka] "+v"(log.ka), [act] "=&s"(act_out), [merged] "+s"(merged_m), [stall] "=&s"(stall) \
+	             : [lim] "v"(lim_a), [fasthi] "v"(fast_hi), [kend] "v"(log.kend), [seg] "v"(seg_a), \
+	               [mask] "v"(mask), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes), [trie] "s"(W.g_trie),             \
+	               [unk] "s"(W.unknown_id), [root] "s"(W.root_base)                                \
+	             : "v24", "v25", "v26", "v27", "s38", "s39", "s40", "s41", "s42", "s43", "vcc",    \
+	               "scc", "memory")
+
 template <bool WIDE>
 __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C, ChunkState S, StreamDev Qd,
                                                          const uint64_t *chunk_first_doc, uint32_t seg_bytes,
@@ -224,6 +360,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	const uint32_t pend_a = lds_addr(log.cells + 64 * kLogDepth + lane);
 	constexpr uint32_t kRow = LaneLog<WIDE>::kRowBytes;
 	const uint32_t tile_a = lds_addr(tile);
+	const uint32_t lds_trie_bytes = T.lds_slots * 8;
 
 	WaveCtx W;
 	W.lds_trie = (const LDS_AS u32x2 *)lds;
@@ -366,36 +503,25 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			// `bound` = the last such end.  The repair then needs no second walk over them.
 			uint32_t mask = 0;
 			uint32_t pa_w = pend_a;
-			uint32_t bound = wk.cp;
-			// The hot loop holds nothing but the walk; it is left whenever a log column is full
-			// or a lane's next token starts past its document limit, both handled out here
-			// (wk.lend > wk.cp tells a lane at a token start from one in the middle of a token,
-			// whose cp may legitimately have reached its limit).
-			for (;;) {
-				bool stall;
-				do {
-					stall = false;
-					if (active) {
-						if (walk_step(W, wk, lim_a)) {
-							log.put(wk.lid);
-							const uint32_t o = wk.cp - seg_a;
-							if (o < 32 && pa_w < pend_a + kPendDepth * kRow) {
-								*lds_ptr<typename Q::entry_t>(pa_w) = (typename Q::entry_t)wk.lid;
-								pa_w += kRow;
-								mask |= 1u << o;
-								bound = wk.cp;
-							}
-							wk.lend = wk.cp + 1;
-							wk.lid = W.unknown_id;
-							active = wk.cp < hi_a;
-							stall = log.ka >= log.kend || (active && wk.cp >= lim_a);
-						}
-					}
-				} while (__builtin_amdgcn_ballot_w64(stall) == 0 && __builtin_amdgcn_ballot_w64(active) != 0);
+			const uint32_t pend_end = pend_a + kPendDepth * kRow;
+			const uint32_t first_a = wk.cp;
+			// The hot loop (assembly, see TOK_ASM_PHASE1) holds nothing but the walk; it is left
+			// whenever a log column is full or a lane's next token starts past its document
+			// limit, both handled out here (wk.lend > wk.cp tells a lane at a token start from
+			// one in the middle of a token, whose cp may legitimately have reached its limit).
+			for (unsigned long long act = __builtin_amdgcn_ballot_w64(active); act != 0;) {
+				// (the compiler takes the loop-carried mask for divergent, hence uniform64() on
+				// the way in and separate in / out operands)
+				unsigned long long stall, act_out;
+				if constexpr (WIDE) TOK_ASM_PHASE1("ds_write_b32", "256");
+				else TOK_ASM_PHASE1("ds_write_b16", "128");
+				(void)stall;
+				act = act_out;
 				log.flush_if_full(Qd, lane);
-				if (has_bounds && active && wk.lend > wk.cp && wk.cp >= lim_a) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
-				if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+				if (has_bounds && ((act >> lane) & 1ull) && wk.lend > wk.cp && wk.cp >= lim_a)
+					lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
 			}
+			const uint32_t bound = mask ? seg_a + (31u - (uint32_t)__builtin_clz(mask)) : first_a;
 			uint32_t cur_exit = nonempty ? wk.cp - hi_a : 0u;
 
 			// ---- phase 2: settle entries ----
@@ -420,27 +546,18 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 					wk.start(pa, W.root_base, W.unknown_id);
 					lim_a = kNoLimit;
 					if (has_bounds && fw) lim_a = tile_a + find_limit(bitmap, pa - tile_a, stop);
-					for (;;) {
-						bool stall;
-						do {
-							stall = false;
-							if (fw) {
-								if (walk_step(W, wk, lim_a)) {
-									log.put(wk.lid);
-									const uint32_t o = wk.cp - seg_a;
-									const bool hit_b = o < 32 && ((mask >> o) & 1u);
-									merged = merged || hit_b;
-									fw = !hit_b && wk.cp < fast_hi;
-									wk.lend = wk.cp + 1;
-									wk.lid = W.unknown_id;
-									stall = log.ka >= log.kend || (fw && wk.cp >= lim_a);
-								}
-							}
-						} while (__builtin_amdgcn_ballot_w64(stall) == 0 && __builtin_amdgcn_ballot_w64(fw) != 0);
+					unsigned long long merged_m = __builtin_amdgcn_ballot_w64(merged);
+					for (unsigned long long act = __builtin_amdgcn_ballot_w64(fw); act != 0;) {
+						unsigned long long stall, act_out;
+						if constexpr (WIDE) TOK_ASM_REPAIR("ds_write_b32", "256");
+						else TOK_ASM_REPAIR("ds_write_b16", "128");
+						(void)stall;
+						act = act_out;
 						log.flush_if_full(Qd, lane);
-						if (has_bounds && fw && wk.lend > wk.cp && wk.cp >= lim_a) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
-						if (__builtin_amdgcn_ballot_w64(fw) == 0) break;
+						if (has_bounds && ((act >> lane) & 1ull) && wk.lend > wk.cp && wk.cp >= lim_a)
+							lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
 					}
+					merged = (merged_m >> lane) & 1ull;
 					pa = wk.cp;
 					// take back the speculative tokens that end at or before the meeting point
 					uint32_t taken = mask;
