@@ -54,6 +54,8 @@ CONFIGS = [
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "300"},       # many mid-document chunk starts
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_SEG": "132", "TOKSCORE_WAVES": "8"},
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_LDS_SLOTS": "300"},   # most trie lookups fall through to L2
+    {"TOKSCORE_SCAN": "generic", "TOKSCORE_CHUNK": "64", "TOKSCORE_NOSNAP": "1"},  # boundaries left mid-token: fix-up kernels
+    {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "300", "TOKSCORE_NOSNAP": "1"},
 ]
 
 

@@ -10,6 +10,10 @@ void launch_scan_generic(const TrieDev &T, const CorpusDev &C, const ChunkState 
                          hipStream_t stream);
 void launch_fixup(const TrieDev &T, const CorpusDev &C, const ChunkState &S, unsigned long long *counts,
                   hipStream_t stream);
+// Moves interior chunk boundaries forward to positions where every greedy chain starts a
+// token (synced[j] = 1), so that those chunks need no entry repair.
+void launch_snap_chunks(const TrieDev &T, const CorpusDev &C, const uint64_t *begin_in, uint64_t *begin_out,
+                        uint32_t *synced, uint32_t nchunks, uint32_t max_len, uint32_t window, hipStream_t stream);
 void launch_finalize(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, hipStream_t stream);
 void launch_tokenize_one(const TrieDev &T, const uint8_t *text, uint64_t n, unsigned long long *ids, uint64_t cap,
                          unsigned long long *n_ids, hipStream_t stream);
@@ -40,6 +44,11 @@ bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num
 void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S, const StreamDev &Q,
                       const TileScanPlan &plan, const uint64_t *chunk_first_doc, uint64_t max_len,
                       hipStream_t stream);
+// Clears out[0 .. V+5), the stream cursor and fill words in one launch and presets
+// out[0] = out[1] = D (START / END once per document) and out[V+4] = total_bytes.
+void launch_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, const StreamDev &Q,
+                    hipStream_t stream);
+// counts += histogram of the token stream; out[V+3] += number of tokens counted.
 void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,
                       uint32_t *slab, uint32_t slab_blocks, hipStream_t stream);
 

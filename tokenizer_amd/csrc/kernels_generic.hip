@@ -14,6 +14,8 @@
 // redone in order (fixup_ordered).  All arithmetic is integer; counts are exact.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace tokscore {
 
 // --- generic scan: one lane per chunk -----------------------------------------------
@@ -116,6 +118,77 @@ __global__ void __launch_bounds__(1024) fixup_ordered_kernel(TrieDev T, CorpusDe
 	}
 }
 
+// --- chunk boundaries at guaranteed token starts ----------------------------------------
+// A position p inside a document is a start of a token of EVERY greedy chain, whatever the
+// chain's own start and whichever tokens are enabled, when no trie path that begins before p
+// reaches past p: the token that covers byte p-1 cannot extend over p, so it ends there.
+// (Trie paths, not ids: a superset of every enabled vocabulary, so toggles keep it valid.)
+// One wave per interior boundary moves it forward to the first such position within `window`
+// bytes (or to the next document start); a chunk that begins there needs no entry repair.
+// reach = max over starts i < p of i + depth(i), depth(i) = length of the longest trie path
+// matching the text at i (clipped at the document end, SolutionFile.cpp:90).
+__global__ void __launch_bounds__(256) snap_chunks_kernel(TrieDev T, CorpusDev C, const uint64_t *begin_in,
+                                                          uint64_t *begin_out, uint32_t *synced, uint32_t nchunks,
+                                                          uint32_t max_len, uint32_t window) {
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+	for (uint32_t j = 1 + wave; j < nchunks; j += nwaves) {
+		const uint64_t b = begin_in[j];
+		const uint64_t dn = next_boundary(C, b); // first document start after b (corpus end if none)
+		uint64_t lo = 0, hi = C.D + 1;           // ds = last document start at or before b
+		while (lo < hi) {
+			const uint64_t mid = (lo + hi) >> 1;
+			if (C.off[mid] <= b) lo = mid + 1;
+			else hi = mid;
+		}
+		const uint64_t ds = C.off[lo - 1];
+		uint64_t p = b;
+		bool ok = ds == b;
+		if (!ok) {
+			const uint64_t back = (b - ds) < (uint64_t)(max_len - 1) ? (b - ds) : (uint64_t)(max_len - 1);
+			const uint64_t last = (dn < b + window) ? dn : b + window - 1; // last candidate position
+			uint64_t carry = 0;
+			for (uint64_t base = b - back; base <= last; base += 64) {
+				const uint64_t i = base + lane;
+				uint64_t r = 0;
+				if (i < dn) {
+					uint32_t nb = T.root_base, d = 0;
+					while (nb != 0 && i + d < dn) {
+						const uint32_t c = lower8(C.bytes[i + d]);
+						const uint2 e = T.slots[nb + c];
+						if ((e.x & kSlotKeyMask) != (c | kSlotValid)) break;
+						d++;
+						nb = e.x >> kSlotBaseShift;
+					}
+					r = i + d;
+				}
+				uint64_t incl = r;
+				for (uint32_t o = 1; o < 64; o <<= 1) {
+					const uint64_t t = __shfl_up(incl, o, 64);
+					if (lane >= o && t > incl) incl = t;
+				}
+				uint64_t excl = __shfl_up(incl, 1, 64);
+				if (lane == 0) excl = 0;
+				if (carry > excl) excl = carry;
+				const bool cand = i >= b && i <= last && excl <= i;
+				const unsigned long long m = __ballot(cand);
+				if (m) {
+					p = base + (uint64_t)__builtin_ctzll(m);
+					ok = true;
+					break;
+				}
+				const uint64_t top = __shfl(incl, 63, 64);
+				if (top > carry) carry = top;
+			}
+		}
+		if (lane == 0) {
+			begin_out[j] = ok ? p : b;
+			synced[j] = ok ? 1u : 0u;
+		}
+	}
+}
+
 // --- finalize: START/END once per document, totals (main.cpp:40-41) -------------------
 // out = counts[V+3] | total_tokens | total_bytes.  One block.
 __global__ void __launch_bounds__(1024) finalize_kernel(unsigned long long *out, uint32_t V, uint64_t D,
@@ -176,6 +249,15 @@ void launch_fixup(const TrieDev &T, const CorpusDev &C, const ChunkState &S, uns
 	hipLaunchKernelGGL(fixup_parallel_kernel, dim3(grid_for(S.nchunks, 256, 8192)), dim3(256), 0, stream, T, C, S, counts);
 	if (S.nchunks > 1)
 		hipLaunchKernelGGL(fixup_ordered_kernel, dim3(1), dim3(1024), 0, stream, T, C, S, counts);
+}
+
+void launch_snap_chunks(const TrieDev &T, const CorpusDev &C, const uint64_t *begin_in, uint64_t *begin_out,
+                        uint32_t *synced, uint32_t nchunks, uint32_t max_len, uint32_t window, hipStream_t stream) {
+	if (nchunks < 2) return;
+	const uint32_t waves = nchunks - 1;
+	const uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, 4096);
+	hipLaunchKernelGGL(snap_chunks_kernel, dim3(blocks), dim3(256), 0, stream, T, C, begin_in, begin_out, synced, nchunks,
+	                   max_len, window);
 }
 
 void launch_finalize(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, hipStream_t stream) {

@@ -669,14 +669,30 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 // counts[id] += sum over slab rows (int32 partials, sign-extended).  grid = (ids / 256, row
 // groups): each thread sums every kReduceGroups-th row and adds its partial with one u64
 // atomic, so the boundary fix-up (which also adds to counts) may run beside this kernel.
+// The partials of ids >= 2 also go to counts[n_ids] (total_tokens, main.cpp:41), one atomic
+// per wave.
 constexpr uint32_t kReduceGroups = 8;
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const uint32_t *slab, uint32_t rows, uint32_t n_ids,
                                                           unsigned long long *counts) {
 	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
-	if (id >= n_ids) return;
 	long long sum = 0;
-	for (uint32_t r = blockIdx.y; r < rows; r += kReduceGroups) sum += (long long)(int32_t)slab[(size_t)r * n_ids + id];
-	if (sum != 0) atomicAdd(&counts[id], (unsigned long long)sum);
+	if (id < n_ids) {
+		for (uint32_t r = blockIdx.y; r < rows; r += kReduceGroups) sum += (long long)(int32_t)slab[(size_t)r * n_ids + id];
+		if (sum != 0) atomicAdd(&counts[id], (unsigned long long)sum);
+	}
+	long long tot = id >= 2 ? sum : 0;
+	for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
+	if ((threadIdx.x & 63) == 0 && tot != 0) atomicAdd(&counts[n_ids], (unsigned long long)tot);
+}
+
+__global__ void __launch_bounds__(256) prepare_kernel(unsigned long long *out, uint32_t V, unsigned long long D,
+                                                      unsigned long long total_bytes, uint32_t *cursor, uint32_t *fill,
+                                                      uint32_t n_fill) {
+	const uint32_t n = gridDim.x * blockDim.x;
+	const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
+	for (uint32_t i = i0; i < V + 5; i += n) out[i] = i < 2 ? D : (i == V + 4 ? total_bytes : 0ull);
+	for (uint32_t i = i0; i < kCursorWords; i += n) cursor[i] = 0;
+	for (uint32_t i = i0; i < n_fill; i += n) fill[i] = 0;
 }
 
 } // namespace
@@ -753,6 +769,12 @@ void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S,
 		                   stream, Tl, C, S, Q, chunk_first_doc, plan.seg_bytes, halo, (uint32_t)max_len, wave_bytes,
 		                   readable_end);
 	}
+}
+
+void launch_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, const StreamDev &Q,
+                    hipStream_t stream) {
+	hipLaunchKernelGGL(prepare_kernel, dim3(128), dim3(256), 0, stream, out, V, (unsigned long long)D,
+	                   (unsigned long long)total_bytes, Q.cursor, Q.fill, Q.capacity_batches);
 }
 
 void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,

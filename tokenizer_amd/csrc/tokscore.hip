@@ -79,6 +79,7 @@ struct tokscore_ctx {
 	uint64_t *d_chunk_first_doc = nullptr;
 	uint32_t *d_chunk_state = nullptr; // entry | exit_a | exit_b
 	uint32_t nchunks = 0;
+	uint32_t unsynced = 0; // chunks whose entry is speculated (not at a guaranteed token start)
 	void *d_stream = nullptr;
 	uint32_t stream_cap_batches = 0;
 	uint32_t *d_fill = nullptr;
@@ -229,6 +230,36 @@ int ensure_plan(tokscore_ctx *c) {
 	HIP_TRY(c, hipMemcpy(c->d_chunk_begin, c->h_chunk_begin.data(), c->h_chunk_begin.size() * sizeof(uint64_t),
 	                     hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_state, (size_t)3 * (c->nchunks + 1) * sizeof(uint32_t)));
+	// Move the boundaries that fell inside a document forward to the next position where every
+	// greedy chain starts a token (kernels_generic.hip: snap_chunks_kernel).  Chunks that begin
+	// there need no entry repair; when all do, an evaluation launches no fix-up kernels at all.
+	c->unsynced = 0;
+	if (c->nchunks > 1 && !env_u64("TOKSCORE_NOSNAP", 0)) {
+		uint64_t *d_new = nullptr;
+		uint32_t *d_syn = nullptr;
+		const size_t nb = c->h_chunk_begin.size();
+		HIP_TRY(c, hipMalloc((void **)&d_new, nb * sizeof(uint64_t)));
+		hipError_t e = hipMalloc((void **)&d_syn, nb * sizeof(uint32_t));
+		std::vector<uint32_t> syn(nb, 1);
+		if (e == hipSuccess) e = hipMemcpy(d_new, c->d_chunk_begin, nb * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+		if (e == hipSuccess) {
+			CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+			const uint32_t window = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->chunk_bytes / 4, 8192));
+			launch_snap_chunks(T, C, c->d_chunk_begin, d_new, d_syn, c->nchunks, (uint32_t)c->packed.max_len, window, c->stream);
+			e = hipStreamSynchronize(c->stream);
+		}
+		if (e == hipSuccess) e = hipMemcpy(c->h_chunk_begin.data(), d_new, nb * sizeof(uint64_t), hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(syn.data() + 1, d_syn + 1, (c->nchunks - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(c->d_chunk_begin, d_new, nb * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+		(void)hipFree(d_new);
+		if (d_syn) (void)hipFree(d_syn);
+		if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("snap_chunks: ") + hipGetErrorString(e));
+		for (uint32_t j = 1; j < c->nchunks; j++) c->unsynced += syn[j] ? 0 : 1;
+	} else {
+		const std::vector<uint64_t> &off = c->h_off;
+		for (uint32_t j = 1; j < c->nchunks; j++)
+			c->unsynced += std::binary_search(off.begin(), off.end(), c->h_chunk_begin[j]) ? 0 : 1;
+	}
 	{
 		std::vector<uint64_t> first(c->nchunks + 1);
 		for (uint32_t j = 0; j <= c->nchunks; j++)
@@ -282,31 +313,37 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	c->ev = c->ring[c->calls % tokscore_ctx::kRing];
 	c->calls++;
 	HIP_TRY(c, hipEventRecord(c->ev[0], s));
-	HIP_TRY(c, hipMemsetAsync(d_out, 0, (c->V + 5) * sizeof(unsigned long long), s));
+	// fix-up kernels only when some chunk starts at a speculated position
+	const bool repair = c->unsynced != 0;
 	if (c->scan_path == 1) {
-		HIP_TRY(c, hipMemsetAsync(c->d_cursor, 0, kCursorWords * sizeof(uint32_t), s));
-		HIP_TRY(c, hipMemsetAsync(c->d_fill, 0, (size_t)c->stream_cap_batches * sizeof(uint32_t), s));
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
+		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s);
 		HIP_TRY(c, hipEventRecord(c->ev[1], s));
 		launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s);
 		HIP_TRY(c, hipEventRecord(c->ev[2], s));
-		// the chunk-boundary fix-up (a few serial walks, latency bound) and the histogram of the
-		// token stream only share d_out, which both update with atomics: run them side by side
-		HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-		HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
-		launch_fixup(T, C, S, d_out, c->side);
-		HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+		if (repair) {
+			// the chunk-boundary fix-up (a few serial walks, latency bound) and the histogram of
+			// the token stream only share d_out, which both update with atomics: side by side
+			HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+			HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
+			launch_fixup(T, C, S, d_out, c->side);
+			HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+		}
 		HIP_TRY(c, hipEventRecord(c->ev[3], s));
 		launch_histogram(Q, c->tile, (uint32_t)c->V, d_out, c->d_slab, c->slab_blocks, s);
-		HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+		if (repair) {
+			HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+			launch_finalize(d_out, (uint32_t)c->V, c->D, c->total, s); // totals again, repairs included
+		}
 	} else {
+		HIP_TRY(c, hipMemsetAsync(d_out, 0, (c->V + 5) * sizeof(unsigned long long), s));
 		HIP_TRY(c, hipEventRecord(c->ev[1], s));
 		launch_scan_generic(T, C, S, d_out, s);
 		HIP_TRY(c, hipEventRecord(c->ev[2], s));
-		launch_fixup(T, C, S, d_out, s);
+		if (repair) launch_fixup(T, C, S, d_out, s);
 		HIP_TRY(c, hipEventRecord(c->ev[3], s));
+		launch_finalize(d_out, (uint32_t)c->V, c->D, c->total, s);
 	}
-	launch_finalize(d_out, (uint32_t)c->V, c->D, c->total, s);
 	HIP_TRY(c, hipEventRecord(c->ev[4], s));
 	HIP_TRY(c, hipGetLastError());
 	c->timing_pending = true;
