@@ -209,11 +209,12 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 // `stall` is non-zero (a log column is full, or a lane's next token starts at or after its
 // document limit), which the C++ around it handles before it re-enters.
 //
-// One trie lookup for the lanes in %[act]: afterwards vcc = lanes whose token goes on
-// (cp and nb already advanced), s[42:43] = lanes whose token is complete, scc = any such.
+// One trie lookup for the lanes in exec (= %[act]); v24 holds each lane's next byte, read
+// at the end of the previous lookup so that its LDS latency hides behind the token-end
+// block.  Afterwards vcc = lanes whose token goes on, s[42:43] = lanes whose token is
+// complete, scc = any such; cp is every lane's next position (after the byte when the token
+// goes on, the next token's start otherwise) and its byte is on the way into v24.
 #define TOK_ASM_LOOKUP(TAG)                                                            \
-	"s_mov_b64 exec, %[act]\n"                                                         \
-	"ds_read_u8 v24, %[cp]\n"                                                          \
 	"s_waitcnt lgkmcnt(0)\n"                                                           \
 	"v_add_lshl_u32 v25, %[nb], v24, 3\n"      /* byte offset of slot nb + c        */ \
 	"v_cmp_gt_u32 vcc, %[ldsb], v25\n"         /* slot staged in LDS?               */ \
@@ -225,13 +226,13 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	"global_load_dwordx2 v[26:27], v25, %[trie]\n" /* cold slot: L2                 */ \
 	".Lhot" TAG "%=:\n"                                                                \
 	"s_mov_b64 exec, %[act]\n"                                                         \
+	"v_or_b32 v24, 0x100, v24\n"               /* (these three while the slot loads) */ \
+	"v_cmp_lt_u32 s[40:41], %[cp], %[lim]\n"   /* byte inside the document          */ \
+	"v_add_u32 %[cp], 1, %[cp]\n"                                                      \
 	"s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                  \
 	"v_and_b32 v25, 0x1ff, v26\n"                                                      \
-	"v_or_b32 v24, 0x100, v24\n"                                                       \
 	"v_cmp_eq_u32 vcc, v25, v24\n"             /* label matches and slot valid      */ \
-	"v_cmp_lt_u32 s[40:41], %[cp], %[lim]\n"   /* byte inside the document          */ \
 	"s_and_b64 s[40:41], s[40:41], vcc\n"      /* hit                               */ \
-	"v_add_u32 %[cp], 1, %[cp]\n"                                                      \
 	"v_cmp_ne_u32 vcc, 0, v27\n"                                                       \
 	"s_and_b64 vcc, vcc, s[40:41]\n"           /* hit on a token end                */ \
 	"v_cndmask_b32 %[lend], %[lend], %[cp], vcc\n"                                     \
@@ -239,28 +240,39 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	"v_lshrrev_b32 %[nb], 9, v26\n"                                                    \
 	"v_cmp_ne_u32 vcc, 0, %[nb]\n"                                                     \
 	"s_and_b64 vcc, vcc, s[40:41]\n"           /* hit on a node with children       */ \
-	"s_andn2_b64 s[42:43], exec, vcc\n"        /* token complete                    */
+	"s_andn2_b64 s[42:43], exec, vcc\n"        /* token complete                    */ \
+	"v_cndmask_b32 %[cp], %[lend], %[cp], vcc\n"                                       \
+	"ds_read_u8 v24, %[cp]\n"
+
+#define TOK_ASM_ENTER                                                                  \
+	"s_mov_b64 s[38:39], exec\n"                                                       \
+	"s_mov_b64 %[act], %[actin]\n"                                                     \
+	"s_mov_b64 exec, %[act]\n"                                                         \
+	"ds_read_u8 v24, %[cp]\n"
+
+// (the byte read in flight targets v24, which the compiler may reuse at once: wait for it)
+#define TOK_ASM_LEAVE                                                                  \
+	"s_waitcnt lgkmcnt(0)\n"                                                           \
+	"s_mov_b64 exec, s[38:39]\n"
 
 // Phase 1 (speculative chain): log the id, remember the token's end while it lies within 32
 // bytes of the segment start, re-arm the walker, retire the lane at its segment end.
 #define TOK_ASM_PHASE1(DSW, ROW)                                                       \
-	asm volatile("s_mov_b64 s[38:39], exec\n"                                          \
-	             "s_mov_b64 %[act], %[actin]\n"                                          \
+	asm volatile(TOK_ASM_ENTER                                                         \
 	             ".Ltop%=:\n" TOK_ASM_LOOKUP("a")                                      \
 	             "s_cbranch_scc0 .Ltop%=\n"                                            \
 	             "s_mov_b64 exec, s[42:43]\n"                                          \
-	             "v_mov_b32 %[cp], %[lend]\n"                                          \
 	             "v_mov_b32 %[nb], %[root]\n"                                          \
 	             DSW " %[ka], %[lid]\n"                                                \
 	             "v_add_u32 %[ka], " ROW ", %[ka]\n"                                   \
-	             "v_sub_u32 v24, %[cp], %[seg]\n"                                      \
-	             "v_cmp_gt_u32 vcc, 32, v24\n"                                         \
+	             "v_sub_u32 v25, %[cp], %[seg]\n"                                      \
+	             "v_cmp_gt_u32 vcc, 32, v25\n"                                         \
 	             "v_cmp_lt_u32 s[40:41], %[pw], %[pwend]\n"                            \
 	             "s_and_b64 vcc, vcc, s[40:41]\n"                                      \
 	             "s_and_b64 exec, exec, vcc\n"                                         \
 	             DSW " %[pw], %[lid]\n"                                                \
 	             "v_add_u32 %[pw], " ROW ", %[pw]\n"                                   \
-	             "v_lshl_or_b32 %[mask], 1, v24, %[mask]\n"                            \
+	             "v_lshl_or_b32 %[mask], 1, v25, %[mask]\n"                            \
 	             "s_mov_b64 exec, s[42:43]\n"                                          \
 	             "v_add_u32 %[lend], 1, %[cp]\n"                                       \
 	             "v_mov_b32 %[lid], %[unk]\n"                                          \
@@ -270,38 +282,36 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	             "v_cmp_ge_u32 s[40:41], %[cp], %[lim]\n"                              \
 	             "s_and_b64 s[40:41], s[40:41], %[act]\n"                              \
 	             "s_or_b64 %[stall], vcc, s[40:41]\n"                                  \
+	             "s_mov_b64 exec, %[act]\n"                                            \
 	             "s_cmp_lg_u64 %[stall], 0\n"                                          \
 	             "s_cbranch_scc1 .Lout%=\n"                                            \
 	             "s_cmp_lg_u64 %[act], 0\n"                                            \
 	             "s_cbranch_scc1 .Ltop%=\n"                                            \
-	             ".Lout%=:\n"                                                          \
-	             "s_mov_b64 exec, s[38:39]\n"                                          \
+	             ".Lout%=:\n" TOK_ASM_LEAVE                                            \
 	             : [cp] "+v"(wk.cp), [nb] "+v"(wk.nb), [lend] "+v"(wk.lend), [lid] "+v"(wk.lid),   \
 	               [ka] "+v"(log.ka), [pw] "+v"(pa_w), [mask] "+v"(mask), [act] "=&s"(act_out),    \
 	               [stall] "=&s"(stall)                                                            \
 	             : [lim] "v"(lim_a), [hi] "v"(hi_a), [kend] "v"(log.kend), [seg] "v"(seg_a),       \
-	               [pwend] "v"(pend_end), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes), [trie] "s"(W.g_trie),        \
-	               [unk] "s"(W.unknown_id), [root] "s"(W.root_base)                                \
+	               [pwend] "v"(pend_end), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes), \
+	               [trie] "s"(W.g_trie), [unk] "s"(W.unknown_id), [root] "s"(W.root_base)          \
 	             : "v24", "v25", "v26", "v27", "s38", "s39", "s40", "s41", "s42", "s43", "vcc",    \
 	               "scc", "memory")
 
 // Phase 2, first round (true chain of a lane whose entry guess was wrong): log the id, stop
 // at the first token end that the speculative chain also had (`mask`) or at `fasthi`.
 #define TOK_ASM_REPAIR(DSW, ROW)                                                       \
-	asm volatile("s_mov_b64 s[38:39], exec\n"                                          \
-	             "s_mov_b64 %[act], %[actin]\n"                                          \
+	asm volatile(TOK_ASM_ENTER                                                         \
 	             ".Ltop%=:\n" TOK_ASM_LOOKUP("b")                                      \
 	             "s_cbranch_scc0 .Ltop%=\n"                                            \
 	             "s_mov_b64 exec, s[42:43]\n"                                          \
-	             "v_mov_b32 %[cp], %[lend]\n"                                          \
 	             "v_mov_b32 %[nb], %[root]\n"                                          \
 	             DSW " %[ka], %[lid]\n"                                                \
 	             "v_add_u32 %[ka], " ROW ", %[ka]\n"                                   \
-	             "v_sub_u32 v24, %[cp], %[seg]\n"                                      \
-	             "v_lshrrev_b32 v25, v24, %[mask]\n"                                   \
-	             "v_and_b32 v25, 1, v25\n"                                             \
-	             "v_cmp_gt_u32 vcc, 32, v24\n"                                         \
-	             "v_cmp_eq_u32 s[40:41], 1, v25\n"                                     \
+	             "v_sub_u32 v25, %[cp], %[seg]\n"                                      \
+	             "v_lshrrev_b32 v26, v25, %[mask]\n"                                   \
+	             "v_and_b32 v26, 1, v26\n"                                             \
+	             "v_cmp_gt_u32 vcc, 32, v25\n"                                         \
+	             "v_cmp_eq_u32 s[40:41], 1, v26\n"                                     \
 	             "s_and_b64 s[40:41], s[40:41], vcc\n"      /* met the counted chain */ \
 	             "s_or_b64 %[merged], %[merged], s[40:41]\n"                           \
 	             "v_cmp_lt_u32 vcc, %[cp], %[fasthi]\n"                                \
@@ -314,17 +324,18 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	             "v_cmp_ge_u32 s[40:41], %[cp], %[lim]\n"                              \
 	             "s_and_b64 s[40:41], s[40:41], %[act]\n"                              \
 	             "s_or_b64 %[stall], vcc, s[40:41]\n"                                  \
+	             "s_mov_b64 exec, %[act]\n"                                            \
 	             "s_cmp_lg_u64 %[stall], 0\n"                                          \
 	             "s_cbranch_scc1 .Lout%=\n"                                            \
 	             "s_cmp_lg_u64 %[act], 0\n"                                            \
 	             "s_cbranch_scc1 .Ltop%=\n"                                            \
-	             ".Lout%=:\n"                                                          \
-	             "s_mov_b64 exec, s[38:39]\n"                                          \
+	             ".Lout%=:\n" TOK_ASM_LEAVE                                            \
 	             : [cp] "+v"(wk.cp), [nb] "+v"(wk.nb), [lend] "+v"(wk.lend), [lid] "+v"(wk.lid),   \
-	               [ka] "+v"(log.ka), [act] "=&s"(act_out), [merged] "+s"(merged_m), [stall] "=&s"(stall) \
+	               [ka] "+v"(log.ka), [act] "=&s"(act_out), [merged] "+s"(merged_m),               \
+	               [stall] "=&s"(stall)                                                            \
 	             : [lim] "v"(lim_a), [fasthi] "v"(fast_hi), [kend] "v"(log.kend), [seg] "v"(seg_a), \
-	               [mask] "v"(mask), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes), [trie] "s"(W.g_trie),             \
-	               [unk] "s"(W.unknown_id), [root] "s"(W.root_base)                                \
+	               [mask] "v"(mask), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes),      \
+	               [trie] "s"(W.g_trie), [unk] "s"(W.unknown_id), [root] "s"(W.root_base)          \
 	             : "v24", "v25", "v26", "v27", "s38", "s39", "s40", "s41", "s42", "s43", "vcc",    \
 	               "scc", "memory")
 
