@@ -47,7 +47,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long x) {
 __device__ __forceinline__ uint32_t lds_addr(const LDS_AS void *p) { return (uint32_t)(uintptr_t)p; }
 template <class T> __device__ __forceinline__ LDS_AS T *lds_ptr(uint32_t a) { return (LDS_AS T *)(uintptr_t)a; }
 constexpr uint32_t kLogDepth = 8; // stream entries per lane per log block
-constexpr uint32_t kPendDepth = 8; // first tokens of a lane's speculative chain remembered for the repair
+constexpr uint32_t kPendDepth = 16; // first tokens of a lane's speculative chain remembered for the repair
 
 __device__ __forceinline__ void wave_sync() {
 	// LDS is in order per wave; this only stops the compiler moving LDS accesses across.
@@ -255,7 +255,7 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	"s_waitcnt lgkmcnt(0)\n"                                                           \
 	"s_mov_b64 exec, s[38:39]\n"
 
-// Phase 1 (speculative chain): log the id, remember the token's end while it lies within 32
+// Phase 1 (speculative chain): log the id, remember the token's end while it lies within 64
 // bytes of the segment start, re-arm the walker, retire the lane at its segment end.
 #define TOK_ASM_PHASE1(DSW, ROW)                                                       \
 	asm volatile(TOK_ASM_ENTER                                                         \
@@ -265,14 +265,18 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	             "v_mov_b32 %[nb], %[root]\n"                                          \
 	             DSW " %[ka], %[lid]\n"                                                \
 	             "v_add_u32 %[ka], " ROW ", %[ka]\n"                                   \
-	             "v_sub_u32 v25, %[cp], %[seg]\n"                                      \
-	             "v_cmp_gt_u32 vcc, 32, v25\n"                                         \
+	             "v_sub_u32 v25, %[cp], %[seg]\n"          /* end offset in segment */ \
+	             "v_cmp_gt_u32 vcc, 64, v25\n"                                         \
 	             "v_cmp_lt_u32 s[40:41], %[pw], %[pwend]\n"                            \
-	             "s_and_b64 vcc, vcc, s[40:41]\n"                                      \
-	             "s_and_b64 exec, exec, vcc\n"                                         \
+	             "s_and_b64 s[40:41], vcc, s[40:41]\n"      /* remembered            */ \
+	             "v_cmp_gt_u32 vcc, 32, v25\n"                                         \
+	             "s_and_b64 exec, s[40:41], vcc\n"                                     \
+	             "v_lshl_or_b32 %[mlo], 1, v25, %[mlo]\n"                              \
+	             "s_andn2_b64 exec, s[40:41], vcc\n"                                   \
+	             "v_lshl_or_b32 %[mhi], 1, v25, %[mhi]\n"  /* shifts by offset - 32 */ \
+	             "s_mov_b64 exec, s[40:41]\n"                                          \
 	             DSW " %[pw], %[lid]\n"                                                \
 	             "v_add_u32 %[pw], " ROW ", %[pw]\n"                                   \
-	             "v_lshl_or_b32 %[mask], 1, v25, %[mask]\n"                            \
 	             "s_mov_b64 exec, s[42:43]\n"                                          \
 	             "v_add_u32 %[lend], 1, %[cp]\n"                                       \
 	             "v_mov_b32 %[lid], %[unk]\n"                                          \
@@ -289,7 +293,8 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	             "s_cbranch_scc1 .Ltop%=\n"                                            \
 	             ".Lout%=:\n" TOK_ASM_LEAVE                                            \
 	             : [cp] "+v"(wk.cp), [nb] "+v"(wk.nb), [lend] "+v"(wk.lend), [lid] "+v"(wk.lid),   \
-	               [ka] "+v"(log.ka), [pw] "+v"(pa_w), [mask] "+v"(mask), [act] "=&s"(act_out),    \
+	               [ka] "+v"(log.ka), [pw] "+v"(pa_w), [mlo] "+v"(mask_lo), [mhi] "+v"(mask_hi),         \
+	               [act] "=&s"(act_out),                                                           \
 	               [stall] "=&s"(stall)                                                            \
 	             : [lim] "v"(lim_a), [hi] "v"(hi_a), [kend] "v"(log.kend), [seg] "v"(seg_a),       \
 	               [pwend] "v"(pend_end), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes), \
@@ -308,9 +313,12 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	             DSW " %[ka], %[lid]\n"                                                \
 	             "v_add_u32 %[ka], " ROW ", %[ka]\n"                                   \
 	             "v_sub_u32 v25, %[cp], %[seg]\n"                                      \
-	             "v_lshrrev_b32 v26, v25, %[mask]\n"                                   \
-	             "v_and_b32 v26, 1, v26\n"                                             \
 	             "v_cmp_gt_u32 vcc, 32, v25\n"                                         \
+	             "s_nop 1\n"                                /* vcc: VALU to VALU     */ \
+	             "v_cndmask_b32 v26, %[mhi], %[mlo], vcc\n"                            \
+	             "v_lshrrev_b32 v26, v25, v26\n"                                       \
+	             "v_and_b32 v26, 1, v26\n"                                             \
+	             "v_cmp_gt_u32 vcc, 64, v25\n"                                         \
 	             "v_cmp_eq_u32 s[40:41], 1, v26\n"                                     \
 	             "s_and_b64 s[40:41], s[40:41], vcc\n"      /* met the counted chain */ \
 	             "s_or_b64 %[merged], %[merged], s[40:41]\n"                           \
@@ -334,7 +342,8 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	               [ka] "+v"(log.ka), [act] "=&s"(act_out), [merged] "+s"(merged_m),               \
 	               [stall] "=&s"(stall)                                                            \
 	             : [lim] "v"(lim_a), [fasthi] "v"(fast_hi), [kend] "v"(log.kend), [seg] "v"(seg_a), \
-	               [mask] "v"(mask), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes),      \
+	               [mlo] "v"(mask_lo), [mhi] "v"(mask_hi), [actin] "s"(uniform64(act)),                \
+	               [ldsb] "s"(lds_trie_bytes),                                                     \
 	               [trie] "s"(W.g_trie), [unk] "s"(W.unknown_id), [root] "s"(W.root_base)          \
 	             : "v24", "v25", "v26", "v27", "s38", "s39", "s40", "s41", "s42", "s43", "vcc",    \
 	               "scc", "memory")
@@ -509,10 +518,10 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			uint32_t lim_a = kNoLimit;
 			bool active = nonempty && wk.cp < hi_a;
 			if (has_bounds && active) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
-			// The ends of the chain's first tokens (at most kPendDepth, within 32 bytes of the
+			// The ends of the chain's first tokens (at most kPendDepth, within 64 bytes of the
 			// segment start) are remembered: end bit in `mask`, id in the lane's pend column;
 			// `bound` = the last such end.  The repair then needs no second walk over them.
-			uint32_t mask = 0;
+			uint32_t mask_lo = 0, mask_hi = 0;
 			uint32_t pa_w = pend_a;
 			const uint32_t pend_end = pend_a + kPendDepth * kRow;
 			const uint32_t first_a = wk.cp;
@@ -532,7 +541,8 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				if (has_bounds && ((act >> lane) & 1ull) && wk.lend > wk.cp && wk.cp >= lim_a)
 					lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
 			}
-			const uint32_t bound = mask ? seg_a + (31u - (uint32_t)__builtin_clz(mask)) : first_a;
+			const unsigned long long mask = ((unsigned long long)mask_hi << 32) | mask_lo;
+			const uint32_t bound = mask ? seg_a + (63u - (uint32_t)__builtin_clzll(mask)) : first_a;
 			uint32_t cur_exit = nonempty ? wk.cp - hi_a : 0u;
 
 			// ---- phase 2: settle entries ----
@@ -552,7 +562,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 					// token ends are in `mask`.  Walk only the true chain until it lands on one of
 					// them: from there on both chains are the same chain.
 					const uint32_t fast_hi = bound < hi_a ? bound : hi_a;
-					bool merged = need && want < 32 && ((mask >> want) & 1u);
+					bool merged = need && want < 64 && ((mask >> (want & 63)) & 1ull);
 					bool fw = need && !merged && pa < fast_hi;
 					wk.start(pa, W.root_base, W.unknown_id);
 					lim_a = kNoLimit;
@@ -571,9 +581,9 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 					merged = (merged_m >> lane) & 1ull;
 					pa = wk.cp;
 					// take back the speculative tokens that end at or before the meeting point
-					uint32_t taken = mask;
-					if (merged) taken &= (2u << ((pa - seg_a) & 31)) - 1u;
-					const uint32_t rank = need ? (uint32_t)__builtin_popcount(taken) : 0u;
+					unsigned long long taken = mask;
+					if (merged) taken &= (2ull << ((pa - seg_a) & 63)) - 1ull;
+					const uint32_t rank = need ? (uint32_t)__builtin_popcountll(taken) : 0u;
 					for (uint32_t jn = 0; __builtin_amdgcn_ballot_w64(jn < rank); jn++) {
 						if (jn < rank) log.put((uint32_t)*lds_ptr<typename Q::entry_t>(pend_a + jn * kRow) | Q::neg);
 						log.flush_if_full(Qd, lane);
@@ -638,10 +648,12 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 	using Q = QTraits<WIDE>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint32_t *bins = reinterpret_cast<uint32_t *>(smem);
+	__shared__ int s_total;
 	const uint32_t lo = blockIdx.y * range_ids;
 	const uint32_t hi = lo + range_ids < n_ids ? lo + range_ids : n_ids;
 	const uint32_t width = hi - lo;
 	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) bins[i] = 0;
+	if (threadIdx.x == 0) s_total = 0;
 	__syncthreads();
 	uint32_t batches = Qd.cursor[0];
 	if (batches > Qd.capacity_batches) batches = Qd.capacity_batches;
@@ -649,6 +661,7 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 	constexpr uint32_t vecs_per_batch = vecs_per_block * kStreamBatch;
 	const uint64_t n_vecs = (uint64_t)batches * vecs_per_batch;
 	const uint4 *vec = reinterpret_cast<const uint4 *>(Qd.blocks);
+	int total = 0; // +1 / -1 per entry seen, whatever its id range
 	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_vecs; i += (uint64_t)gridDim.x * blockDim.x) {
 		// blocks past fill[batch] were handed out but never written
 		const uint32_t bt = (uint32_t)(i / vecs_per_batch);
@@ -661,39 +674,46 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 			if (WIDE) {
 				const uint32_t e = wds[k];
 				const uint32_t id = e & 0x7FFFFFFFu;
-				if (id >= lo && id < hi) atomicAdd(&bins[id - lo], (e & Q::neg) ? 0xFFFFFFFFu : 1u);
+				const int sgn = (e & Q::neg) ? -1 : 1;
+				total += sgn;
+				if (id >= lo && id < hi) atomicAdd(&bins[id - lo], (uint32_t)sgn);
 			} else {
 #pragma unroll
 				for (int h = 0; h < 2; h++) {
 					const uint32_t e = (wds[k] >> (16 * h)) & 0xFFFFu;
 					const uint32_t id = e & 0x7FFFu;
-					if (id != Q::null_entry && id >= lo && id < hi) atomicAdd(&bins[id - lo], (e & Q::neg) ? 0xFFFFFFFFu : 1u);
+					if (id == Q::null_entry) continue;
+					const int sgn = (e & Q::neg) ? -1 : 1;
+					total += sgn;
+					if (id >= lo && id < hi) atomicAdd(&bins[id - lo], (uint32_t)sgn);
 				}
 			}
 		}
 	}
+	// the row's extra column n_ids: this workgroup's token total (main.cpp:41), from the
+	// first id range only so that it is counted once
+	if (blockIdx.y == 0) {
+		for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+		if ((threadIdx.x & 63) == 0 && total != 0) atomicAdd(&s_total, total);
+	}
 	__syncthreads();
-	uint32_t *row = slab + (size_t)blockIdx.x * n_ids + lo;
-	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) row[i] = bins[i];
+	uint32_t *row = slab + (size_t)blockIdx.x * (n_ids + 1);
+	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) row[lo + i] = bins[i];
+	if (blockIdx.y == 0 && threadIdx.x == 0) row[n_ids] = (uint32_t)s_total;
 }
 
-// counts[id] += sum over slab rows (int32 partials, sign-extended).  grid = (ids / 256, row
+// counts[id] += sum over slab rows (int32 partials, sign-extended); column n_ids of a row is
+// its token total and lands in counts[n_ids] = total_tokens.  grid = (columns / 256, row
 // groups): each thread sums every kReduceGroups-th row and adds its partial with one u64
 // atomic, so the boundary fix-up (which also adds to counts) may run beside this kernel.
-// The partials of ids >= 2 also go to counts[n_ids] (total_tokens, main.cpp:41), one atomic
-// per wave.
 constexpr uint32_t kReduceGroups = 8;
-__global__ void __launch_bounds__(256) slab_reduce_kernel(const uint32_t *slab, uint32_t rows, uint32_t n_ids,
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const uint32_t *slab, uint32_t rows, uint32_t n_cols,
                                                           unsigned long long *counts) {
 	const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= n_cols) return;
 	long long sum = 0;
-	if (id < n_ids) {
-		for (uint32_t r = blockIdx.y; r < rows; r += kReduceGroups) sum += (long long)(int32_t)slab[(size_t)r * n_ids + id];
-		if (sum != 0) atomicAdd(&counts[id], (unsigned long long)sum);
-	}
-	long long tot = id >= 2 ? sum : 0;
-	for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
-	if ((threadIdx.x & 63) == 0 && tot != 0) atomicAdd(&counts[n_ids], (unsigned long long)tot);
+	for (uint32_t r = blockIdx.y; r < rows; r += kReduceGroups) sum += (long long)(int32_t)slab[(size_t)r * n_cols + id];
+	if (sum != 0) atomicAdd(&counts[id], (unsigned long long)sum);
 }
 
 __global__ void __launch_bounds__(256) prepare_kernel(unsigned long long *out, uint32_t V, unsigned long long D,
@@ -737,9 +757,10 @@ bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num
 		const uint32_t n_vec = (tile_cap + 15) / 16;
 		const uint32_t bm_words = (tile_cap + 31) / 32 + 1;
 		wave_bytes = n_vec * 16 + ((bm_words * 4 + 15) & ~15u) + stream_block_bytes(wide) + 64 * kPendDepth * (wide ? 4 : 2);
-		if ((uint64_t)wave_bytes * waves + 8 * 1024 <= lds_total) break;
+		// (how much of the trie sits in LDS matters little: some lane of 64 misses anyway)
+		if ((uint64_t)wave_bytes * waves + 2 * 1024 <= lds_total) break;
 		if (waves == 1) return false;
-		waves >>= 1; // long segments: fewer waves so that the tiles still fit
+		waves -= waves > 8 ? 2 : 1; // long segments / wide ids: fewer waves so that the tiles still fit
 	}
 	uint32_t lds_budget = lds_total;
 	if (const char *s = getenv("TOKSCORE_BLOCKS_PER_CU")) lds_budget = lds_total / std::max(1, atoi(s)) - 512;
@@ -803,8 +824,8 @@ void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, 
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		hipLaunchKernelGGL(hist_kernel<false>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab);
 	}
-	hipLaunchKernelGGL(slab_reduce_kernel, dim3((n_ids + 255) / 256, kReduceGroups), dim3(256), 0, stream, slab,
-	                   slab_blocks, n_ids, counts);
+	hipLaunchKernelGGL(slab_reduce_kernel, dim3((n_ids + 1 + 255) / 256, kReduceGroups), dim3(256), 0, stream, slab,
+	                   slab_blocks, n_ids + 1, counts);
 }
 
 } // namespace tokscore
