@@ -411,6 +411,20 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 		uint32_t chunk_exit = 0;
 
 		uint64_t a0 = begin & ~15ull; // 16-byte aligned tile base
+		// The chunk is cut into equal tiles: as few as fit the LDS tile, each with the same
+		// lane segment length (4 * odd bytes, longer than any token), so that no chunk ends
+		// in a nearly empty tile.
+		uint32_t seg_c = seg_bytes;
+		{
+			const uint64_t len = end - a0;
+			const uint64_t nt = (len + tile_span - 1) / tile_span;
+			const uint32_t per = (uint32_t)((len + nt - 1) / nt);
+			seg_c = 4 * ((((per + 63) / 64 + 3) / 4) | 1u);
+			if (seg_c < min_seg) seg_c = min_seg;
+			if (seg_c > seg_bytes) seg_c = seg_bytes;
+		}
+		const uint32_t span_c = 64 * seg_c;                           // bytes owned by one tile of this chunk
+		const uint32_t n_vec_c = (span_c + halo_bytes + 16 + 15) / 16; // 16-byte vectors staged per tile
 		u32x4 pre[kMaxVec];
 		auto load_tile_regs = [&](uint64_t base_abs) {
 #pragma unroll
@@ -418,7 +432,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				const uint32_t v = lane + 64 * i;
 				const uint64_t a = base_abs + (uint64_t)v * 16;
 				u32x4 x = {0, 0, 0, 0};
-				if (v < n_vec && a + 16 <= readable_end) x = *reinterpret_cast<const u32x4 *>(C.bytes + a);
+				if (v < n_vec_c && a + 16 <= readable_end) x = *reinterpret_cast<const u32x4 *>(C.bytes + a);
 				pre[i] = x;
 			}
 		};
@@ -431,7 +445,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 #pragma unroll
 				for (int i = 0; i < kMaxVec; i++) {
 					const uint32_t v = lane + 64 * i;
-					if (v < n_vec) {
+					if (v < n_vec_c) {
 						u32x4 x = pre[i];
 						x.x = lower4(x.x);
 						x.y = lower4(x.y);
@@ -440,10 +454,10 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 						((LDS_AS u32x4 *)tile)[v] = x;
 					}
 				}
-				const uint64_t next_a0 = a0 + tile_span;
+				const uint64_t next_a0 = a0 + span_c;
 				if (next_a0 < end) load_tile_regs(next_a0); // in flight while this tile is walked
 			} else {
-				for (uint32_t v = lane; v < n_vec; v += 64) {
+				for (uint32_t v = lane; v < n_vec_c; v += 64) {
 					const uint64_t a = a0 + (uint64_t)v * 16;
 					u32x4 x = {0, 0, 0, 0};
 					if (a + 16 <= readable_end) x = *reinterpret_cast<const u32x4 *>(C.bytes + a);
@@ -459,8 +473,8 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			{
 				// offsets are sorted, so the ones inside [a0, a0 + tile_cap) are a run starting at
 				// di; di itself advances to the first offset at/after the NEXT tile's base
-				const uint64_t tile_end_abs = a0 + tile_cap;
-				const uint64_t next_abs = a0 + tile_span;
+				const uint64_t tile_end_abs = a0 + (uint64_t)n_vec_c * 16;
+				const uint64_t next_abs = a0 + span_c;
 				uint64_t scan = di;
 				bool di_done = false;
 				bool zeroed = false;
@@ -494,15 +508,15 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			// ---- phase 1: speculative chain per lane segment ----
 			const uint32_t off0 = (uint32_t)(begin > a0 ? begin - a0 : 0); // only the chunk's first tile
 			const uint64_t rem = end - a0;
-			const uint32_t tile_hi = rem < tile_span ? (uint32_t)rem : tile_span;
-			// a chunk's last, partial tile is cut into shorter segments (still 4 * odd bytes and
-			// longer than any token) so that as many lanes as possible share it
-			uint32_t seg_t = seg_bytes;
-			if (tile_hi < tile_span) {
+			const uint32_t tile_hi = rem < span_c ? (uint32_t)rem : span_c;
+			// the chunk's last tile may still be a little short: shorter segments again, so
+			// that as many lanes as possible share it
+			uint32_t seg_t = seg_c;
+			if (tile_hi < span_c) {
 				const uint32_t dw = ((tile_hi + 63) / 64 + 3) / 4;
 				seg_t = 4 * (dw | 1u);
 				if (seg_t < min_seg) seg_t = min_seg;
-				if (seg_t > seg_bytes) seg_t = seg_bytes;
+				if (seg_t > seg_c) seg_t = seg_c;
 			}
 			const uint32_t seg_nom = lane * seg_t;
 			uint32_t seg_lo = seg_nom > off0 ? seg_nom : off0;
@@ -629,7 +643,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			const uint32_t last = 63u - (uint32_t)__builtin_clzll(ne); // lane 0 is always non-empty
 			chunk_exit = __shfl(cur_exit, last, 64);
 			carry = chunk_exit;
-			a0 += tile_span;
+			a0 += span_c;
 		}
 		if (lane == 0) {
 			S.entry[j] = 0;

@@ -141,11 +141,13 @@ void free_plan(tokscore_ctx *c) {
 	c->plan_valid = false;
 }
 
-// Work chunks: cut every ~chunk_bytes, snapped forward to a document start when one is
-// within half a chunk (then the chunk's entry is certain and needs no repair) -- the
-// same unit of independence the reference parallelises over (main.cpp:38-43).  Long
-// documents are cut mid-text and repaired by the fix-up kernels.
-void build_chunks(tokscore_ctx *c, uint64_t chunk_bytes) {
+// Work chunks, the unit the scan's work queue hands out -- the same unit of independence the
+// reference parallelises over (main.cpp:38-43), cut finer.  With `uniform` the cuts are at
+// multiples of chunk_bytes (ensure_plan then moves each one forward to a guaranteed token
+// start, so chunks stay equal in size and need no repair).  Otherwise a cut is snapped
+// forward to a document start when one is within half a chunk (its entry is then certain);
+// the rest are cut mid-text and repaired by the fix-up kernels.
+void build_chunks(tokscore_ctx *c, uint64_t chunk_bytes, bool uniform) {
 	std::vector<uint64_t> &b = c->h_chunk_begin;
 	b.clear();
 	b.push_back(0);
@@ -153,9 +155,11 @@ void build_chunks(tokscore_ctx *c, uint64_t chunk_bytes) {
 	uint64_t pos = 0;
 	while (pos + chunk_bytes + chunk_bytes / 2 < c->total) {
 		const uint64_t target = pos + chunk_bytes;
-		auto it = std::lower_bound(off.begin(), off.end(), target);
 		uint64_t next = target;
-		if (it != off.end() && *it - target <= chunk_bytes / 2 && *it < c->total) next = *it;
+		if (!uniform) {
+			auto it = std::lower_bound(off.begin(), off.end(), target);
+			if (it != off.end() && *it - target <= chunk_bytes / 2 && *it < c->total) next = *it;
+		}
 		b.push_back(next);
 		pos = next;
 	}
@@ -213,18 +217,20 @@ int ensure_plan(tokscore_ctx *c) {
 	c->scan_path = tile_ok ? 1 : 0;
 	if (!tile_ok) c->tile = TileScanPlan{};
 	uint64_t dflt_chunk = 2048;
+	const bool snap = !env_u64("TOKSCORE_NOSNAP", 0);
 	if (tile_ok) {
-		// a few chunks per resident wave, so the atomic work queue can balance the tail
+		// Equal chunks, a whole number of them per resident wave (the queue then hands every
+		// wave the same amount of work), each one LDS tile: a little under the tile's capacity,
+		// because the snap below moves a boundary forward by some tens of bytes.
 		const uint64_t waves = (uint64_t)c->tile.blocks * c->tile.waves_per_block;
-		// and a whole number of tiles per chunk, so that only snapped chunks end in a partial tile
-		const uint64_t tile_span = 64ull * c->tile.seg_bytes;
-		const uint64_t tiles = std::min<uint64_t>(16, std::max<uint64_t>(2, c->total / (waves * 4) / tile_span));
-		dflt_chunk = tiles * tile_span;
+		const uint64_t nominal = 64ull * (c->tile.seg_bytes - 8);
+		const uint64_t per_wave = std::max<uint64_t>(1, (c->total + waves * nominal - 1) / (waves * nominal));
+		dflt_chunk = std::max<uint64_t>(nominal / 4, (c->total + waves * per_wave - 1) / (waves * per_wave));
 	}
 	c->chunk_bytes = env_u64("TOKSCORE_CHUNK", dflt_chunk);
 	if (c->chunk_bytes < 64) c->chunk_bytes = 64;
 	if (c->chunk_bytes < 4 * c->packed.max_len) c->chunk_bytes = 4 * c->packed.max_len;
-	build_chunks(c, c->chunk_bytes);
+	build_chunks(c, c->chunk_bytes, snap);
 	c->nchunks = (uint32_t)(c->h_chunk_begin.size() - 1);
 	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_begin, c->h_chunk_begin.size() * sizeof(uint64_t)));
 	HIP_TRY(c, hipMemcpy(c->d_chunk_begin, c->h_chunk_begin.data(), c->h_chunk_begin.size() * sizeof(uint64_t),
@@ -234,7 +240,7 @@ int ensure_plan(tokscore_ctx *c) {
 	// greedy chain starts a token (kernels_generic.hip: snap_chunks_kernel).  Chunks that begin
 	// there need no entry repair; when all do, an evaluation launches no fix-up kernels at all.
 	c->unsynced = 0;
-	if (c->nchunks > 1 && !env_u64("TOKSCORE_NOSNAP", 0)) {
+	if (c->nchunks > 1 && snap) {
 		uint64_t *d_new = nullptr;
 		uint32_t *d_syn = nullptr;
 		const size_t nb = c->h_chunk_begin.size();
@@ -244,7 +250,7 @@ int ensure_plan(tokscore_ctx *c) {
 		if (e == hipSuccess) e = hipMemcpy(d_new, c->d_chunk_begin, nb * sizeof(uint64_t), hipMemcpyDeviceToDevice);
 		if (e == hipSuccess) {
 			CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
-			const uint32_t window = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->chunk_bytes / 4, 8192));
+			const uint32_t window = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->chunk_bytes - 1, 8192));
 			launch_snap_chunks(T, C, c->d_chunk_begin, d_new, d_syn, c->nchunks, (uint32_t)c->packed.max_len, window, c->stream);
 			e = hipStreamSynchronize(c->stream);
 		}
