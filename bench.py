@@ -70,6 +70,24 @@ def cpu_baseline(corpus, off, tokens, sample_bytes=32_000_000):
     return out
 
 
+def measured_traffic(workload_bytes):
+    """HBM bytes per scan launch from the newest committed rocprofv3 --pmc summary of this same
+    command (tools/refresh_profiles.sh + tools/summarize_profiles.py; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE).  None when there is none or it
+    was taken on another shard size."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+            bench = json.loads(open(f.replace("_pmc.json", "_bench.json")).read().strip().splitlines()[-1])
+        except (OSError, ValueError):
+            continue
+        if "traffic_bytes_per_launch" in d and bench.get("config", {}).get("bytes_per_gpu") == workload_bytes:
+            return float(d["traffic_bytes_per_launch"]), os.path.relpath(f, ROOT)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +165,7 @@ def main():
         alg_bytes = int(info.corpus_bytes) + 8 * (V + 3)
         scan_avg_ms = float(np.mean(scan_ms))
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(int(info.corpus_bytes))
         rec = {
             "metric": "corpus GB/s scored per full-vocab eval",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,7 +180,7 @@ def main():
                        "parallelism": "documents sharded over %d GPU(s), 1 count all-reduce" % world},
             "roofline": {"bound": "hbm", "kernel": "scan_tile_kernel" if info.scan_path == 1 else "scan_generic_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "alg_bytes_per_launch": alg_bytes, "kernel_ms": scan_avg_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": scan_avg_ms,
                          "eval_kernels_ms": float(np.mean(eval_ms))},
             "total_tokens": int(host[V + 3]), "h2d_inclusive_GBps": info.corpus_bytes / (h2d_s + elapsed / args.steps) / 1e9,
         }
