@@ -1,5 +1,6 @@
 """GPU parity: the HIP path (through the C-ABI) against the reference-generated goldens
 and against the CPU oracle on seeded synthetic corpora.  Bit-exact: integer work only."""
+import json
 import os
 
 import numpy as np
@@ -175,3 +176,30 @@ def test_toggle_equals_full_rescore_of_the_toggled_vocabulary():
     again = s.score()
     assert np.array_equal(again[0], base[0]) and again[1:] == base[1:]
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ascii_caps", "dup_tokens", "nul_doc", "cjk_unknown"])
+def test_reference_flow_through_file_mirrors(case):
+    """main.cpp:26-46 as the reference writes it: SolutionFile + DataFile + Tokenize per
+    article, against what the compiled reference printed for the same two files."""
+    from tokenizer_amd import files
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", case)
+    tkn = files.SolutionFile(os.path.join(d, "tokens.json"))
+    test = files.DataFile(os.path.join(d, "shard.json"))
+    assert tkn.IsValid() and test.IsValid()
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    init_size = comp_size = 0
+    for article, ids in zip(test.GetEntries(), exp["ids"]):
+        init_size += len(article.text)
+        got = tkn.Tokenize(article.text)
+        comp_size += len(got) - 2
+        assert got == [files.UNKNOWN if i < 0 else i for i in ids]
+    assert init_size == exp["total_bytes"] and comp_size == exp["total_tokens"]
+    counts, tt, tb = files.score_shard(tkn, test)
+    assert (tt, tb) == (exp["total_tokens"], exp["total_bytes"])
+    for k, v in exp["counts"].items():
+        idx = len(tkn.tokens) + 2 if int(k) < 0 else int(k)
+        assert int(counts[idx]) == v
+    assert int(counts.sum()) == sum(exp["counts"].values())
+    tkn.close()

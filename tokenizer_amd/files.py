@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's file classes on the scoring path.
+
+    SolutionFile  -- /root/reference/src/files/SolutionFile.{h,cpp}: the vocabulary
+                     (`.tokens.json`), its id assignment, GetId / GetToken / Tokenize
+    DataFile      -- /root/reference/src/files/DataFile.{h,cpp}: one corpus shard
+    score_shard   -- /root/reference/src/main.cpp:31-46: the scoring loop over a shard
+
+Same names, argument meaning and error behaviour as the reference: a file that cannot be
+read or does not validate leaves the object with IsValid() == False, nothing is thrown
+(JsonFile.h:17, JsonFile.cpp:14-29).  All segmentation runs on the GPU through the C-ABI
+(libtokscore.so); there is no CPU path in here.
+"""
+import json
+
+import numpy as np
+
+from . import Scorer
+
+BUILD_VERSION = "0.4.0"  # /root/reference/src/config.h:3
+START_TOKEN = "<START>"  # SolutionFile.cpp:10
+END_TOKEN = "<END>"      # SolutionFile.cpp:11
+UNKNOWN = (1 << 64) - 1  # (size_t)-1, SolutionFile.cpp:76,93
+
+_SHORT_ESCAPES = {0x08: "\\b", 0x0C: "\\f", 0x0A: "\\n", 0x0D: "\\r", 0x09: "\\t", 0x22: '\\"', 0x5C: "\\\\"}
+
+
+def _json_string(s: str) -> str:
+    """A JSON string exactly as rapidjson's Writer prints it (writer.h WriteString): only
+    '"', '\\' and control characters are escaped, the rest is raw UTF-8."""
+    out = ['"']
+    for ch in s:
+        o = ord(ch)
+        if o in _SHORT_ESCAPES:
+            out.append(_SHORT_ESCAPES[o])
+        elif o < 0x20:
+            out.append("\\u%04X" % o)
+        else:
+            out.append(ch)
+    out.append('"')
+    return "".join(out)
+
+
+def _load_json(path):
+    try:
+        with open(path, "rb") as f:
+            return json.loads(f.read().decode("utf-8"))
+    except (OSError, ValueError):
+        return None
+
+
+def _utf8(s: str):
+    try:
+        return s.encode("utf-8")
+    except UnicodeEncodeError:  # lone surrogate: rapidjson rejects the file (JsonFile.cpp:26)
+        return None
+
+
+class SolutionFile:
+    """SolutionFile(path) reads a `.tokens.json`; SolutionFile(tokens, path) assigns ids to
+    `tokens` and writes the file (SolutionFile.cpp:43-72).  Ids: 0 = <START>, 1 = <END>,
+    token i = i + 2; a repeated string keeps its first id (:56,69)."""
+
+    def __init__(self, tokens_or_path, path=None, device: int = 0):
+        self._device = device
+        self._scorer = None
+        self._ids = {}
+        self.tokens = []  # bytes, in file order
+        self.max_len_ = 0
+        self.valid_ = False
+        if path is None:
+            self.path_ = tokens_or_path
+            doc = _load_json(self.path_)
+            if not self._validate(doc):
+                return
+            toks = [_utf8(t) for t in doc["tokens"]]
+            if any(t is None for t in toks):
+                return
+            self.tokens = toks
+            self.valid_ = True
+        else:
+            self.path_ = path
+            self.tokens = [t if isinstance(t, bytes) else t.encode("utf-8") for t in tokens_or_path]
+            self._build_doc()
+            # (the reference leaves valid_ false on this constructor, JsonFile.cpp:16-17, and uses
+            # the object all the same, main.cpp:26-46)
+        for i, t in enumerate(self.tokens):
+            self.max_len_ = max(self.max_len_, len(t))
+            self._ids.setdefault(t, i + 2)
+
+    @staticmethod
+    def _validate(doc) -> bool:  # SolutionFile.cpp:14-26
+        if not isinstance(doc, dict):
+            return False
+        if not isinstance(doc.get("version"), str) or doc["version"] != BUILD_VERSION:
+            return False
+        if not isinstance(doc.get("tokens"), list):
+            return False
+        return all(isinstance(t, str) for t in doc["tokens"])
+
+    def _build_doc(self):  # SolutionFile.cpp:27-41 + JsonFile::Save (JsonFile.cpp:35-46)
+        body = ", ".join(_json_string(t.decode("utf-8")) for t in self.tokens)
+        text = '{\n    "version": %s,\n    "tokens": [%s]\n}' % (_json_string(BUILD_VERSION), body)
+        with open(self.path_, "wb") as f:
+            f.write(text.encode("utf-8"))
+
+    def IsValid(self) -> bool:
+        return self.valid_
+
+    def GetId(self, token) -> int:  # SolutionFile.cpp:74-77
+        t = token if isinstance(token, bytes) else token.encode("utf-8")
+        return self._ids.get(t, UNKNOWN)
+
+    def GetToken(self, id_: int) -> str:  # SolutionFile.cpp:79-81
+        if id_ == UNKNOWN:
+            return "<UNKNOWN>"
+        if id_ == 0:
+            return START_TOKEN
+        if id_ == 1:
+            return END_TOKEN
+        return self.tokens[id_ - 2].decode("utf-8", errors="replace")
+
+    def scorer(self) -> Scorer:
+        """The GPU context that holds this vocabulary (created on first use)."""
+        if self._scorer is None:
+            s = Scorer(self._device)
+            s.set_vocab_list(self.tokens)
+            self._scorer = s
+        return self._scorer
+
+    def Tokenize(self, text):  # SolutionFile.cpp:83-100, on the GPU
+        data = text if isinstance(text, bytes) else text.encode("utf-8")
+        return [UNKNOWN if i < 0 else i for i in self.scorer().tokenize(data)]
+
+    def close(self):
+        if self._scorer is not None:
+            self._scorer.close()
+            self._scorer = None
+
+
+class DataFile:
+    """One corpus shard: a JSON array of {"id", "title", "text"} objects (DataFile.cpp:3-22)."""
+
+    class Entry:
+        __slots__ = ("id", "title", "text")
+
+        def __init__(self, id_, title, text):
+            self.id, self.title, self.text = id_, title, text
+
+    def __init__(self, path):
+        self.path_ = path
+        self.valid_ = False
+        self._entries = []
+        doc = _load_json(path)
+        if not self._validate(doc):
+            return
+        entries = []
+        for e in doc:
+            # GetString() hands a C string to std::string: cut at the first NUL (DataFile.cpp:27-29)
+            fields = [_utf8(e[k].split("\x00", 1)[0]) for k in ("id", "title", "text")]
+            if any(f is None for f in fields):
+                return
+            entries.append(DataFile.Entry(*fields))
+        self._entries = entries
+        self.valid_ = True
+
+    @staticmethod
+    def _validate(doc) -> bool:  # DataFile.cpp:3-17
+        if not isinstance(doc, list) or not doc:
+            return False
+        for e in doc:
+            if not isinstance(e, dict):
+                return False
+            if not all(isinstance(e.get(k), str) for k in ("id", "text", "title")):
+                return False
+        return True
+
+    def IsValid(self) -> bool:
+        return self.valid_
+
+    def GetEntries(self):  # DataFile.cpp:24-31 (owning copies)
+        return list(self._entries)
+
+    def packed(self):
+        """The shard as the C-ABI takes it: document bytes back to back + D + 1 offsets."""
+        texts = [e.text for e in self._entries]
+        off = np.zeros(len(texts) + 1, dtype=np.uint64)
+        if texts:
+            off[1:] = np.cumsum([len(t) for t in texts], dtype=np.uint64)
+        corpus = np.frombuffer(b"".join(texts), dtype=np.uint8) if off[-1] else np.zeros(0, dtype=np.uint8)
+        return corpus, off
+
+
+def score_shard(solution: SolutionFile, shard: DataFile):
+    """main.cpp:31-46 over one shard: (counts[V+3], total_tokens = comp_size, total_bytes =
+    init_size); counts[id] for ids 0..V+1, counts[V+2] = UNKNOWN."""
+    s = solution.scorer()
+    s.set_corpus(*shard.packed())
+    return s.score()
