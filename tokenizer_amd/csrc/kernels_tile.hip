@@ -41,6 +41,7 @@ __device__ __forceinline__ unsigned long long uniform64(unsigned long long x) {
 	const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
 	return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ uint32_t uniform32(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // LDS pointers are 32-bit byte addresses; the walk keeps its positions as such addresses so
 // that a byte read needs no address arithmetic.
@@ -91,30 +92,37 @@ __device__ __forceinline__ uint32_t find_limit(const LDS_AS uint32_t *bm, uint32
 	return kNoLimit;
 }
 
-// The wave's log block in LDS: cell (k, lane) at [k * 64 + lane]; lane `lane` owns column
-// `lane` and fills it top down.  Written to the stream as it stands (order is irrelevant to
-// a histogram), null cells included.
+// The wave's log block in LDS: 64 * kLogDepth entries filled front to back.  The lanes that
+// complete a token in a step append together: each takes the slot cur + (its rank among them),
+// cur advances by their number -- all scalar / mbcnt arithmetic, no LDS atomics.  The block
+// goes to the stream when the next step might not fit (cur > capacity - 64); unused cells are
+// null entries (order is irrelevant to a histogram).
 template <bool WIDE> struct LaneLog {
 	using Q = QTraits<WIDE>;
-	static constexpr uint32_t kRowBytes = 64 * sizeof(typename Q::entry_t);
+	static constexpr uint32_t kEntries = 64 * kLogDepth;
+	static constexpr uint32_t kHigh = kEntries - 64; // flush above this fill
+	static constexpr uint32_t kShift = WIDE ? 2 : 1;  // log2(entry bytes)
 	LDS_AS typename Q::entry_t *cells;
-	uint32_t ka;   // per lane: LDS address of the next free cell of this lane's column
-	uint32_t kend; // per lane: LDS address one past the column
+	uint32_t cur; // wave uniform: entries used
 
 	__device__ __forceinline__ void init(LDS_AS typename Q::entry_t *c, uint32_t lane) {
 		cells = c;
-		kend = lds_addr(c + lane) + kLogDepth * kRowBytes;
 		clear(lane);
 	}
 	__device__ __forceinline__ void clear(uint32_t lane) {
-		constexpr uint32_t words = 64 * kLogDepth * sizeof(typename Q::entry_t) / 4;
+		constexpr uint32_t words = kEntries * sizeof(typename Q::entry_t) / 4;
 		LDS_AS uint32_t *w = (LDS_AS uint32_t *)cells;
 		for (uint32_t i = lane; i < words; i += 64) w[i] = Q::null_word;
-		ka = kend - kLogDepth * kRowBytes;
+		cur = 0;
 	}
-	__device__ __forceinline__ void put(uint32_t val) {
-		*lds_ptr<typename Q::entry_t>(ka) = (typename Q::entry_t)val;
-		ka += kRowBytes;
+	// wave-uniform call: the lanes with `pred` append `val`
+	__device__ __forceinline__ void put(bool pred, uint32_t val) {
+		const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+		if (pred) {
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+			cells[cur + rank] = (typename Q::entry_t)val;
+		}
+		cur += (uint32_t)__builtin_popcountll(m);
 	}
 	// Stream space is handed out in batches of kStreamBatch blocks, so the single
 	// allocation word sees one atomic per batch, not per block (one word sustains only
@@ -124,7 +132,7 @@ template <bool WIDE> struct LaneLog {
 
 	// wave-uniform call: send the block out and start an empty one
 	__device__ __forceinline__ void flush(const StreamDev &S, uint32_t lane) {
-		constexpr uint32_t vecs = 64 * kLogDepth * sizeof(typename Q::entry_t) / 16; // 16-byte vectors
+		constexpr uint32_t vecs = kEntries * sizeof(typename Q::entry_t) / 16; // 16-byte vectors
 		if (used == kStreamBatch) {
 			if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = kStreamBatch;
 			uint32_t b = 0;
@@ -145,10 +153,10 @@ template <bool WIDE> struct LaneLog {
 		wave_sync();
 	}
 	__device__ __forceinline__ void flush_if_full(const StreamDev &S, uint32_t lane) {
-		if (__builtin_amdgcn_ballot_w64(ka >= kend)) flush(S, lane);
+		if (cur > kHigh) flush(S, lane);
 	}
 	__device__ __forceinline__ void finish(const StreamDev &S, uint32_t lane) {
-		if (__builtin_amdgcn_ballot_w64(ka != kend - kLogDepth * kRowBytes)) flush(S, lane);
+		if (cur != 0) flush(S, lane);
 		if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = used;
 	}
 };
@@ -247,6 +255,7 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 #define TOK_ASM_ENTER                                                                  \
 	"s_mov_b64 s[38:39], exec\n"                                                       \
 	"s_mov_b64 %[act], %[actin]\n"                                                     \
+	"s_mov_b32 %[cur], %[curin]\n"                                                     \
 	"s_mov_b64 exec, %[act]\n"                                                         \
 	"ds_read_u8 v24, %[cp]\n"
 
@@ -255,16 +264,38 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	"s_waitcnt lgkmcnt(0)\n"                                                           \
 	"s_mov_b64 exec, s[38:39]\n"
 
+// The lanes in exec (= s[42:43], the lanes that completed a token) append their ids to the log.
+#define TOK_ASM_APPEND(DSW, SHIFT)                                                     \
+	"v_mbcnt_lo_u32_b32 v25, s42, 0\n"                                                 \
+	"v_mbcnt_hi_u32_b32 v25, s43, v25\n"       /* rank among them                   */ \
+	"v_add_u32 v25, %[cur], v25\n"                                                     \
+	"v_lshl_add_u32 v25, v25, " SHIFT ", %[logb]\n"                                    \
+	DSW " v25, %[lid]\n"                                                               \
+	"s_bcnt1_i32_b64 s40, s[42:43]\n"                                                  \
+	"s_add_u32 %[cur], %[cur], s40\n"
+
+// Leave the loop when a lane's next token starts at or after its document limit, when the
+// log may not take another step, or when no lane walks any more.
+#define TOK_ASM_NEXT(HIGH)                                                             \
+	"v_cmp_ge_u32 s[40:41], %[cp], %[lim]\n"                                           \
+	"s_and_b64 %[stall], s[40:41], %[act]\n"                                           \
+	"s_mov_b64 exec, %[act]\n"                                                         \
+	"s_cbranch_scc1 .Lout%=\n"                                                         \
+	"s_cmp_gt_u32 %[cur], " HIGH "\n"                                                  \
+	"s_cbranch_scc1 .Lout%=\n"                                                         \
+	"s_cmp_lg_u64 %[act], 0\n"                                                         \
+	"s_cbranch_scc1 .Ltop%=\n"                                                         \
+	".Lout%=:\n"
+
 // Phase 1 (speculative chain): log the id, remember the token's end while it lies within 64
 // bytes of the segment start, re-arm the walker, retire the lane at its segment end.
-#define TOK_ASM_PHASE1(DSW, ROW)                                                       \
+#define TOK_ASM_PHASE1(DSW, ROW, SHIFT, HIGH)                                                       \
 	asm volatile(TOK_ASM_ENTER                                                         \
 	             ".Ltop%=:\n" TOK_ASM_LOOKUP("a")                                      \
 	             "s_cbranch_scc0 .Ltop%=\n"                                            \
 	             "s_mov_b64 exec, s[42:43]\n"                                          \
 	             "v_mov_b32 %[nb], %[root]\n"                                          \
-	             DSW " %[ka], %[lid]\n"                                                \
-	             "v_add_u32 %[ka], " ROW ", %[ka]\n"                                   \
+	             TOK_ASM_APPEND(DSW, SHIFT)                                            \
 	             "v_sub_u32 v25, %[cp], %[seg]\n"          /* end offset in segment */ \
 	             "v_cmp_gt_u32 vcc, 64, v25\n"                                         \
 	             "v_cmp_lt_u32 s[40:41], %[pw], %[pwend]\n"                            \
@@ -282,21 +313,12 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	             "v_mov_b32 %[lid], %[unk]\n"                                          \
 	             "v_cmp_ge_u32 vcc, %[cp], %[hi]\n"                                    \
 	             "s_andn2_b64 %[act], %[act], vcc\n"                                   \
-	             "v_cmp_ge_u32 vcc, %[ka], %[kend]\n"                                  \
-	             "v_cmp_ge_u32 s[40:41], %[cp], %[lim]\n"                              \
-	             "s_and_b64 s[40:41], s[40:41], %[act]\n"                              \
-	             "s_or_b64 %[stall], vcc, s[40:41]\n"                                  \
-	             "s_mov_b64 exec, %[act]\n"                                            \
-	             "s_cmp_lg_u64 %[stall], 0\n"                                          \
-	             "s_cbranch_scc1 .Lout%=\n"                                            \
-	             "s_cmp_lg_u64 %[act], 0\n"                                            \
-	             "s_cbranch_scc1 .Ltop%=\n"                                            \
-	             ".Lout%=:\n" TOK_ASM_LEAVE                                            \
+	             TOK_ASM_NEXT(HIGH) TOK_ASM_LEAVE                                      \
 	             : [cp] "+v"(wk.cp), [nb] "+v"(wk.nb), [lend] "+v"(wk.lend), [lid] "+v"(wk.lid),   \
-	               [ka] "+v"(log.ka), [pw] "+v"(pa_w), [mlo] "+v"(mask_lo), [mhi] "+v"(mask_hi),         \
-	               [act] "=&s"(act_out),                                                           \
-	               [stall] "=&s"(stall)                                                            \
-	             : [lim] "v"(lim_a), [hi] "v"(hi_a), [kend] "v"(log.kend), [seg] "v"(seg_a),       \
+	               [pw] "+v"(pa_w), [mlo] "+v"(mask_lo), [mhi] "+v"(mask_hi), [act] "=&s"(act_out),   \
+	               [cur] "=&s"(cur_out), [stall] "=&s"(stall)                                         \
+	             : [lim] "v"(lim_a), [hi] "v"(hi_a), [seg] "v"(seg_a), [curin] "s"(uniform32(log.cur)), \
+	               [logb] "s"(log_a),                                                              \
 	               [pwend] "v"(pend_end), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes), \
 	               [trie] "s"(W.g_trie), [unk] "s"(W.unknown_id), [root] "s"(W.root_base)          \
 	             : "v24", "v25", "v26", "v27", "s38", "s39", "s40", "s41", "s42", "s43", "vcc",    \
@@ -304,14 +326,13 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 
 // Phase 2, first round (true chain of a lane whose entry guess was wrong): log the id, stop
 // at the first token end that the speculative chain also had (`mask`) or at `fasthi`.
-#define TOK_ASM_REPAIR(DSW, ROW)                                                       \
+#define TOK_ASM_REPAIR(DSW, ROW, SHIFT, HIGH)                                                       \
 	asm volatile(TOK_ASM_ENTER                                                         \
 	             ".Ltop%=:\n" TOK_ASM_LOOKUP("b")                                      \
 	             "s_cbranch_scc0 .Ltop%=\n"                                            \
 	             "s_mov_b64 exec, s[42:43]\n"                                          \
 	             "v_mov_b32 %[nb], %[root]\n"                                          \
-	             DSW " %[ka], %[lid]\n"                                                \
-	             "v_add_u32 %[ka], " ROW ", %[ka]\n"                                   \
+	             TOK_ASM_APPEND(DSW, SHIFT)                                            \
 	             "v_sub_u32 v25, %[cp], %[seg]\n"                                      \
 	             "v_cmp_gt_u32 vcc, 32, v25\n"                                         \
 	             "s_nop 1\n"                                /* vcc: VALU to VALU     */ \
@@ -328,20 +349,12 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	             "s_or_b64 %[act], %[act], vcc\n"                                      \
 	             "v_add_u32 %[lend], 1, %[cp]\n"                                       \
 	             "v_mov_b32 %[lid], %[unk]\n"                                          \
-	             "v_cmp_ge_u32 vcc, %[ka], %[kend]\n"                                  \
-	             "v_cmp_ge_u32 s[40:41], %[cp], %[lim]\n"                              \
-	             "s_and_b64 s[40:41], s[40:41], %[act]\n"                              \
-	             "s_or_b64 %[stall], vcc, s[40:41]\n"                                  \
-	             "s_mov_b64 exec, %[act]\n"                                            \
-	             "s_cmp_lg_u64 %[stall], 0\n"                                          \
-	             "s_cbranch_scc1 .Lout%=\n"                                            \
-	             "s_cmp_lg_u64 %[act], 0\n"                                            \
-	             "s_cbranch_scc1 .Ltop%=\n"                                            \
-	             ".Lout%=:\n" TOK_ASM_LEAVE                                            \
+	             TOK_ASM_NEXT(HIGH) TOK_ASM_LEAVE                                      \
 	             : [cp] "+v"(wk.cp), [nb] "+v"(wk.nb), [lend] "+v"(wk.lend), [lid] "+v"(wk.lid),   \
-	               [ka] "+v"(log.ka), [act] "=&s"(act_out), [merged] "+s"(merged_m),               \
+	               [act] "=&s"(act_out), [merged] "+s"(merged_m), [cur] "=&s"(cur_out),             \
 	               [stall] "=&s"(stall)                                                            \
-	             : [lim] "v"(lim_a), [fasthi] "v"(fast_hi), [kend] "v"(log.kend), [seg] "v"(seg_a), \
+	             : [lim] "v"(lim_a), [fasthi] "v"(fast_hi), [seg] "v"(seg_a),                      \
+	               [curin] "s"(uniform32(log.cur)), [logb] "s"(log_a),                             \
 	               [mlo] "v"(mask_lo), [mhi] "v"(mask_hi), [actin] "s"(uniform64(act)),                \
 	               [ldsb] "s"(lds_trie_bytes),                                                     \
 	               [trie] "s"(W.g_trie), [unk] "s"(W.unknown_id), [root] "s"(W.root_base)          \
@@ -378,7 +391,8 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	log.init((LDS_AS typename Q::entry_t *)(wbase + n_vec * 16 + ((bm_words * 4 + 15) & ~15u)), lane);
 	// ids of the first kPendDepth tokens of every lane's speculative chain, cell (j, lane)
 	const uint32_t pend_a = lds_addr(log.cells + 64 * kLogDepth + lane);
-	constexpr uint32_t kRow = LaneLog<WIDE>::kRowBytes;
+	const uint32_t log_a = uniform32(lds_addr(log.cells));
+	constexpr uint32_t kRow = 64 * sizeof(typename Q::entry_t);
 	const uint32_t tile_a = lds_addr(tile);
 	const uint32_t lds_trie_bytes = T.lds_slots * 8;
 
@@ -547,10 +561,12 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				// (the compiler takes the loop-carried mask for divergent, hence uniform64() on
 				// the way in and separate in / out operands)
 				unsigned long long stall, act_out;
-				if constexpr (WIDE) TOK_ASM_PHASE1("ds_write_b32", "256");
-				else TOK_ASM_PHASE1("ds_write_b16", "128");
+				uint32_t cur_out;
+				if constexpr (WIDE) TOK_ASM_PHASE1("ds_write_b32", "256", "2", "448");
+				else TOK_ASM_PHASE1("ds_write_b16", "128", "1", "448");
 				(void)stall;
 				act = act_out;
+				log.cur = cur_out;
 				log.flush_if_full(Qd, lane);
 				if (has_bounds && ((act >> lane) & 1ull) && wk.lend > wk.cp && wk.cp >= lim_a)
 					lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
@@ -584,10 +600,12 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 					unsigned long long merged_m = __builtin_amdgcn_ballot_w64(merged);
 					for (unsigned long long act = __builtin_amdgcn_ballot_w64(fw); act != 0;) {
 						unsigned long long stall, act_out;
-						if constexpr (WIDE) TOK_ASM_REPAIR("ds_write_b32", "256");
-						else TOK_ASM_REPAIR("ds_write_b16", "128");
+						uint32_t cur_out;
+						if constexpr (WIDE) TOK_ASM_REPAIR("ds_write_b32", "256", "2", "448");
+						else TOK_ASM_REPAIR("ds_write_b16", "128", "1", "448");
 						(void)stall;
 						act = act_out;
+						log.cur = cur_out;
 						log.flush_if_full(Qd, lane);
 						if (has_bounds && ((act >> lane) & 1ull) && wk.lend > wk.cp && wk.cp >= lim_a)
 							lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
@@ -599,7 +617,8 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 					if (merged) taken &= (2ull << ((pa - seg_a) & 63)) - 1ull;
 					const uint32_t rank = need ? (uint32_t)__builtin_popcountll(taken) : 0u;
 					for (uint32_t jn = 0; __builtin_amdgcn_ballot_w64(jn < rank); jn++) {
-						if (jn < rank) log.put((uint32_t)*lds_ptr<typename Q::entry_t>(pend_a + jn * kRow) | Q::neg);
+						const uint32_t row = jn < rank ? jn : 0u;
+						log.put(jn < rank, (uint32_t)*lds_ptr<typename Q::entry_t>(pend_a + row * kRow) | Q::neg);
 						log.flush_if_full(Qd, lane);
 					}
 					// not met yet: the generic dual walk below continues from (pa, bound)
@@ -610,27 +629,21 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				wk.start(on_a ? pa : pb, W.root_base, W.unknown_id);
 				lim_a = kNoLimit;
 				if (has_bounds && walking) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
-				for (;;) {
-					bool stall;
-					do {
-						stall = false;
-						if (walking) {
-							if (walk_step(W, wk, lim_a)) {
-								log.put(on_a ? wk.lid : (wk.lid | Q::neg));
-								pa = on_a ? wk.cp : pa;
-								pb = on_a ? pb : wk.cp;
-								walking = pa != pb && (pa < hi_a || pb < hi_a);
-								on_a = pa < pb;
-								wk.cp = on_a ? pa : pb;
-								wk.lend = wk.cp + 1;
-								wk.lid = W.unknown_id;
-								stall = log.ka >= log.kend || (walking && wk.cp >= lim_a);
-							}
-						}
-					} while (__builtin_amdgcn_ballot_w64(stall) == 0 && __builtin_amdgcn_ballot_w64(walking) != 0);
+				while (__builtin_amdgcn_ballot_w64(walking)) {
+					bool fin = false;
+					if (walking) fin = walk_step(W, wk, lim_a);
+					log.put(fin, on_a ? wk.lid : (wk.lid | Q::neg));
+					if (fin) {
+						pa = on_a ? wk.cp : pa;
+						pb = on_a ? pb : wk.cp;
+						walking = pa != pb && (pa < hi_a || pb < hi_a);
+						on_a = pa < pb;
+						wk.cp = on_a ? pa : pb;
+						wk.lend = wk.cp + 1;
+						wk.lid = W.unknown_id;
+						if (has_bounds && walking && wk.cp >= lim_a) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
+					}
 					log.flush_if_full(Qd, lane);
-					if (has_bounds && walking && wk.lend > wk.cp && wk.cp >= lim_a) lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
-					if (__builtin_amdgcn_ballot_w64(walking) == 0) break;
 				}
 				if (need) {
 					cur_entry = want;
