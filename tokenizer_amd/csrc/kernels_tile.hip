@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(256) prepare_kernel(unsigned long long *out, u
 uint32_t stream_block_bytes(uint32_t wide_ids) { return 64 * kLogDepth * (wide_ids ? 4 : 2); }
 
 bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num_cus, TileScanPlan *plan) {
-	static const uint32_t kSeg[] = {36, 52, 68, 100, 132, 196, 260, 516, 1028};
+	static const uint32_t kSeg[] = {36, 52, 68, 84, 92, 100, 116, 132, 196, 260, 516, 1028};
 	uint32_t seg = 0;
 	uint32_t want_seg = 100;
 	if (const char *s = getenv("TOKSCORE_SEG")) want_seg = (uint32_t)atoi(s);
