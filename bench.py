@@ -105,9 +105,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # BENCH_REHEARSAL=1: all ranks on GPU 0 over gloo -- exercises the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); never used for a reported number.
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -130,7 +138,12 @@ def main():
     def step():
         scorer.score_async(out.data_ptr(), stream.cuda_stream)
         if world > 1:
-            dist.all_reduce(out)
+            if rehearsal:  # gloo: reduce a host copy
+                host_copy = out.cpu()
+                dist.all_reduce(host_copy)
+                out.copy_(host_copy)
+            else:
+                dist.all_reduce(out)
 
     def fence():
         torch.cuda.synchronize()
@@ -153,7 +166,7 @@ def main():
     eval_ms = [t[0] for t in tm]
     scan_ms = [t[1] for t in tm]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -170,7 +183,7 @@ def main():
             "metric": "corpus GB/s scored per full-vocab eval",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else ""),
             "config": {"workload": "configs[1]: wiki-like %.0f MB shard per GPU (seed 20201120+rank), "
                                    "one full-vocabulary scoring pass, V=%d" % (args.mb, V),
                        "docs_per_gpu": int(info.corpus_docs), "bytes_per_gpu": int(info.corpus_bytes),
