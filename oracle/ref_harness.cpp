@@ -238,15 +238,35 @@ static int cmd_dag(int argc, char **argv) {
 	return 0;
 }
 
+// cands <dir> <max_len> <out.json>: the candidate list GetTokens builds from the shards of
+// <dir> (GetTokens.cpp:92-115), names and uses (= Trie freq, Trie.cpp:82) in its own order.
+static int cmd_cands(int argc, char **argv) {
+	if (argc < 5) return 2;
+	const std::string dir = argv[2];
+	const int max_len = atoi(argv[3]);
+	MetadataFile metadata(dir + "/.metadata.json", true);
+	std::vector<annealing::Token> tokens = annealing::GetTokens(metadata, (uint8_t)max_len, -1, true);
+	std::ofstream out(argv[4]);
+	out << "{\"max_len\": " << max_len << ",\n \"tokens\": [";
+	for (size_t i = 0; i < tokens.size(); i++) {
+		out << (i ? ",\n  [" : "\n  [");
+		json_escape(out, tokens[i].GetName());
+		out << ", " << (uint64_t)tokens[i].l_branch_.uses << "]";
+	}
+	out << "]}\n";
+	return 0;
+}
+
 int main(int argc, char **argv) {
 	if (argc < 2) {
-		std::cerr << "usage: ref_harness score|anneal|dag ..." << std::endl;
+		std::cerr << "usage: ref_harness score|anneal|dag|cands ..." << std::endl;
 		return 2;
 	}
 	const std::string cmd = argv[1];
 	if (cmd == "score") return cmd_score(argc, argv);
 	if (cmd == "anneal") return cmd_anneal(argc, argv);
 	if (cmd == "dag") return cmd_dag(argc, argv);
+	if (cmd == "cands") return cmd_cands(argc, argv);
 	std::cerr << "unknown command " << cmd << std::endl;
 	return 2;
 }

@@ -208,3 +208,99 @@ void ora_score(const ora_vocab *v, const uint8_t *corpus, const uint64_t *off,
 	free(jobs);
 	free(tid);
 }
+
+/* ---- closed-vocabulary all-occurrence counting (GetTokens.cpp:21-27, Trie.cpp:114-128) ---- */
+
+static int seq_len(uint8_t lead) { /* utf8/core.h:134-147 */
+	if (lead < 0x80) return 1;
+	if ((lead >> 5) == 0x6) return 2;
+	if ((lead >> 4) == 0xe) return 3;
+	if ((lead >> 3) == 0x1e) return 4;
+	return 0;
+}
+
+typedef struct {
+	const ora_vocab *v;
+	const uint8_t *corpus;
+	const uint64_t *off;
+	uint64_t d0, d1;
+	uint32_t max_cp;
+	uint64_t *counts;
+	uint64_t positions;
+} count_job;
+
+static void *count_range(void *arg) {
+	count_job *j = (count_job *)arg;
+	uint64_t cap = 0;
+	for (uint64_t d = j->d0; d < j->d1; d++) {
+		uint64_t n = j->off[d + 1] - j->off[d];
+		if (n > cap) cap = n;
+	}
+	uint64_t *start = (uint64_t *)malloc((cap + 1) * sizeof(uint64_t));
+	for (uint64_t d = j->d0; d < j->d1; d++) {
+		const uint8_t *text = j->corpus + j->off[d];
+		const uint64_t n = j->off[d + 1] - j->off[d];
+		/* utf8to32: one code point per lead byte (GetTokens.cpp:22-23) */
+		uint64_t ncp = 0, p = 0;
+		while (p < n) {
+			int l = seq_len(text[p]);
+			if (l == 0) l = 1; /* unchecked::next: no case taken, ++it */
+			start[ncp++] = p;
+			p += (uint64_t)l;
+		}
+		if (p > n) p = n; /* (truncated tail: outside the contract) */
+		start[ncp] = p;
+		j->positions += ncp;
+		for (uint64_t i = 0; i < ncp; i++) { /* GetTokens.cpp:24-26 */
+			uint64_t len = ncp - i < j->max_cp ? ncp - i : j->max_cp;
+			for (uint64_t k = 1; k <= len; k++) { /* Trie.cpp:118-124: every prefix gets ++freq */
+				uint64_t id = ora_get_id(j->v, text + start[i], start[i + k] - start[i]);
+				if (id != ORA_UNKNOWN) j->counts[id]++;
+			}
+		}
+	}
+	free(start);
+	return NULL;
+}
+
+void ora_count_occurrences(const ora_vocab *v, const uint8_t *corpus, const uint64_t *off,
+                           uint64_t D, uint32_t max_cp, uint64_t *counts, uint64_t *positions,
+                           int threads) {
+	uint64_t nc = v->V + 3;
+	memset(counts, 0, nc * sizeof(uint64_t));
+	if (threads < 1) threads = 1;
+	if ((uint64_t)threads > D) threads = D ? (int)D : 1;
+	count_job *jobs = (count_job *)calloc(threads, sizeof *jobs);
+	pthread_t *tid = (pthread_t *)calloc(threads, sizeof *tid);
+	uint64_t total = D ? off[D] - off[0] : 0;
+	uint64_t d = 0;
+	for (int t = 0; t < threads; t++) {
+		jobs[t].v = v;
+		jobs[t].corpus = corpus;
+		jobs[t].off = off;
+		jobs[t].max_cp = max_cp;
+		jobs[t].d0 = d;
+		uint64_t target = off[0] + total / threads * (t + 1);
+		if (t == threads - 1) d = D;
+		else
+			while (d < D && off[d + 1] <= target) d++;
+		jobs[t].d1 = d;
+		jobs[t].counts = t == 0 ? counts : (uint64_t *)calloc(nc, sizeof(uint64_t));
+	}
+	if (threads == 1) count_range(&jobs[0]);
+	else {
+		for (int t = 0; t < threads; t++) pthread_create(&tid[t], NULL, count_range, &jobs[t]);
+		for (int t = 0; t < threads; t++) pthread_join(tid[t], NULL);
+	}
+	uint64_t pos = 0;
+	for (int t = 0; t < threads; t++) {
+		pos += jobs[t].positions;
+		if (t) {
+			for (uint64_t i = 0; i < nc; i++) counts[i] += jobs[t].counts[i];
+			free(jobs[t].counts);
+		}
+	}
+	if (positions) *positions = pos;
+	free(jobs);
+	free(tid);
+}

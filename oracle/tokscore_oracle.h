@@ -57,6 +57,23 @@ void ora_score(const ora_vocab *v, const uint8_t *corpus, const uint64_t *off,
                uint64_t D, uint64_t *counts, uint64_t *total_tokens,
                uint64_t *total_bytes, int threads);
 
+/* Closed-vocabulary all-occurrence counting: annealing::ExtractCandidates +
+ * Trie::AddString (/root/reference/src/tokenizer/GetTokens.cpp:21-27,
+ * Trie.cpp:114-128) restricted to the strings of `v`: every document is cut
+ * into code points (utf8::unchecked::utf8to32; lead byte -> sequence length as
+ * utf8/core.h:134-147), and for every code-point position i and every length
+ * k = 1 .. min(remaining, max_cp) code points the string [i, i+k) gets +1 if
+ * it is in the vocabulary.  NO lower-casing on this path.  counts has V+3
+ * entries indexed by id like ora_score (ids 0, 1 and V+2 stay 0); a duplicate
+ * string counts on its first id.  *positions = number of code-point positions
+ * (the trie root's freq, Trie.cpp:117).  Valid UTF-8 only: the reference's
+ * unchecked decoder reads past the end of a truncated sequence.
+ * Pinned by tests/golden/cands_* and dag_tiny.json (Token uses == freq,
+ * Trie.cpp:82). */
+void ora_count_occurrences(const ora_vocab *v, const uint8_t *corpus, const uint64_t *off,
+                           uint64_t D, uint32_t max_cp, uint64_t *counts, uint64_t *positions,
+                           int threads);
+
 #ifdef __cplusplus
 }
 #endif

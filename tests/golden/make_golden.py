@@ -79,6 +79,29 @@ def docs_of(corpus, off):
     return [b[int(off[i]):int(off[i + 1])].decode("utf-8") for i in range(len(off) - 1)]
 
 
+def gen_cands():
+    # (13) f1: the candidate list (names + uses = occurrence counts) GetTokens builds from a
+    # small mixed shard: ASCII words, CJK, 2- and 4-byte characters, a short and an empty-ish doc.
+    texts = docs_of(*synth.wiki_like(2_500, seed=11, n_words=300, median_doc=400))
+    texts += docs_of(*synth.cjk_heavy(1_200, seed=12, doc_lo=64, doc_hi=600))
+    texts += ["Ünïcödé 𝄞𝄞 clef", "a", "aaaaaaaaaaaaaaaaaaaaaaaa"]
+    with tempfile.TemporaryDirectory() as tmp:
+        data = os.path.join(tmp, "data")
+        os.makedirs(data)
+        write_shard(os.path.join(data, "a.json"), texts)
+        out = os.path.join(tmp, "cands.json")
+        subprocess.run([HARNESS, "cands", data, "6", out], check=True, cwd=tmp, stdout=subprocess.DEVNULL)
+        j = json.load(open(out))
+    d = os.path.join(HERE, "cands_mixed")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    with gzip.GzipFile(os.path.join(d, "cands.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps({"max_len": j["max_len"], "docs": texts, "tokens": j["tokens"]},
+                           separators=(",", ":"), ensure_ascii=False).encode("utf-8"))
+    print("cands_mixed candidates=%d docs=%d" % (len(j["tokens"]), len(texts)))
+
+
+
 def main():
     if not os.path.exists(HARNESS):
         sys.exit("build oracle/_ref/ref_harness first (make -C oracle)")
@@ -176,6 +199,11 @@ def main():
             json.dump(j, f, separators=(",", ":"), ensure_ascii=False)
         print("dag_tiny tokens=%d steps=%d" % (len(j["tokens"]), len(j["steps"])))
 
+    gen_cands()
+
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["cands"]:  # only the f1 case (the annealed cases are not reproducible bit for bit)
+        gen_cands()
+    else:
+        main()

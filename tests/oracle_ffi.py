@@ -39,6 +39,7 @@ def lib():
         L.ora_tokenize.restype = C.c_uint64
         L.ora_tokenize.argtypes = [C.c_void_p, u8p, C.c_uint64, u64p]
         L.ora_score.argtypes = [C.c_void_p, u8p, u64p, C.c_uint64, u64p, u64p, u64p, C.c_int]
+        L.ora_count_occurrences.argtypes = [C.c_void_p, u8p, u64p, C.c_uint64, C.c_uint32, u64p, u64p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -95,6 +96,19 @@ class OracleVocab:
         return counts, int(tt.value), int(tb.value)
 
 
+    def count_occurrences(self, corpus: np.ndarray, doc_off: np.ndarray, max_cp: int, threads: int = 1):
+        """-> (counts[V+3] by id, code-point positions); GetTokens.cpp:21-27 on a closed vocabulary."""
+        corpus = np.ascontiguousarray(corpus, dtype=np.uint8)
+        if corpus.size == 0:
+            corpus = np.zeros(1, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        counts = np.zeros(self.V + 3, dtype=np.uint64)
+        pos = C.c_uint64(0)
+        lib().ora_count_occurrences(self._h, _p8(corpus), _p64(doc_off), len(doc_off) - 1, max_cp, _p64(counts),
+                                    C.byref(pos), threads)
+        return counts, int(pos.value)
+
+
 def _read_json(path):
     if os.path.exists(path):
         with open(path, "rb") as f:
@@ -104,7 +118,19 @@ def _read_json(path):
 
 
 def golden_cases():
-    return sorted(d for d in os.listdir(GOLDEN) if os.path.isdir(os.path.join(GOLDEN, d)))
+    """The scoring cases (tokens + shard + what the compiled reference printed for them)."""
+    return sorted(d for d in os.listdir(GOLDEN) if os.path.isdir(os.path.join(GOLDEN, d))
+                  and (os.path.exists(os.path.join(GOLDEN, d, "tokens.json"))
+                       or os.path.exists(os.path.join(GOLDEN, d, "tokens.json.gz"))))
+
+
+def load_cands(name):
+    """A candidate-list golden (ref_harness `cands`): dict(max_len, docs=list[bytes],
+    names=list[bytes], uses=np.uint64[n]) in the reference's own candidate order."""
+    j = _read_json(os.path.join(GOLDEN, name, "cands.json"))
+    return {"max_len": int(j["max_len"]), "docs": [t.encode("utf-8") for t in j["docs"]],
+            "names": [t[0].encode("utf-8") for t in j["tokens"]],
+            "uses": np.array([t[1] for t in j["tokens"]], dtype=np.uint64)}
 
 
 def load_golden(name):
