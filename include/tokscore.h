@@ -108,6 +108,19 @@ int tokscore_score_async(tokscore_ctx *ctx, void *d_out, void *stream);
 int tokscore_score_incremental(tokscore_ctx *ctx, uint64_t *counts, uint64_t *total_tokens,
                                uint64_t *total_bytes);
 
+/* Closed-vocabulary all-occurrence counting: what
+ * annealing::ExtractCandidates + Trie::AddString (src/tokenizer/GetTokens.cpp:21-27,
+ * src/tokenizer/Trie.cpp:114-128) add up for the strings of the vocabulary -- for every
+ * code-point position of every document of the resident corpus and every window of
+ * 1 .. max_cp code points starting there (clipped at the document end), the window's string
+ * gets +1 if it is an enabled vocabulary string.  These are the `uses` GetTokens seeds each
+ * Token with (Trie.cpp:82).  No lower-casing on this path; the corpus must be valid UTF-8
+ * (the reference's unchecked decoder is undefined otherwise).
+ *   counts[V+3]   indexed by id like tokscore_score: counts[i + 2] for token i (a repeated
+ *                 string counts on its first id); counts[0], counts[1], counts[V+2] are 0
+ *   positions     number of code-point positions (the trie root's freq, Trie.cpp:117) */
+int tokscore_count_occurrences(tokscore_ctx *ctx, uint32_t max_cp, uint64_t *counts, uint64_t *positions);
+
 /* Per-document id sequence, the exact return value of
  * SolutionFile::Tokenize(std::string) (src/files/SolutionFile.cpp:83-100) for one
  * document of raw bytes; UNKNOWN is UINT64_MAX as in the reference.  ids_out has room

@@ -1,0 +1,77 @@
+"""f1 on the GPU: tokscore_count_occurrences against the compiled reference's candidate list
+(golden) and against the CPU oracle on synthetic corpora.  Bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import tokenizer_amd as ta
+from tokenizer_amd import synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _gpu_counts(names, docs_or_packed, max_cp):
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(names))
+        packed = docs_or_packed if isinstance(docs_or_packed, tuple) else synth.pack_docs(docs_or_packed)
+        s.set_corpus(*packed)
+        out = s.count_occurrences(max_cp)
+        again = s.count_occurrences(max_cp)
+        assert np.array_equal(out[0], again[0]) and out[1] == again[1]
+    finally:
+        s.close()
+    return out
+
+
+def test_counts_equal_reference_uses_mixed():
+    g = O.load_cands("cands_mixed")
+    counts, positions = _gpu_counts(g["names"], g["docs"], g["max_len"])
+    bad = np.nonzero(counts[2:2 + len(g["names"])] != g["uses"])[0]
+    assert bad.size == 0, (bad[:10], [g["names"][i] for i in bad[:10]], counts[2 + bad[:10]], g["uses"][bad[:10]])
+    assert positions == sum(len(d.decode("utf-8")) for d in g["docs"])
+    assert counts[0] == counts[1] == counts[-1] == 0
+
+
+def test_counts_equal_reference_uses_dag_tiny():
+    j = json.load(open(os.path.join(HERE, "golden", "dag_tiny.json"), encoding="utf-8"))
+    names = [t["name"].encode("utf-8") for t in j["tokens"]]
+    uses = np.array([t["uses"] for t in j["tokens"]], dtype=np.uint64)
+    docs = ["abracadabra abracadabra", "the cat sat on the mat", "日本語の本 日本"]
+    counts, _ = _gpu_counts(names, [d.encode("utf-8") for d in docs], j["max_len"])
+    assert np.array_equal(counts[2:2 + len(names)], uses)
+
+
+@pytest.mark.parametrize("kind,max_cp,V", [("wiki", 10, 8000), ("cjk", 6, 6000), ("utf8", 4, 40000), ("wiki", 2, 3000)])
+def test_counts_equal_oracle_on_synthetic(kind, max_cp, V):
+    if kind == "wiki":
+        corpus, off = synth.wiki_like(1_500_000, seed=3)
+        tokens = synth.build_vocab(corpus[:400_000], V, lowercase=False)
+    elif kind == "cjk":
+        corpus, off = synth.cjk_heavy(1_000_000, seed=4)
+        tokens = synth.build_vocab(corpus[:300_000], V)
+    else:
+        corpus, off = synth.random_utf8(1_500_000, seed=6, doc_lo=64, doc_hi=60_000)
+        tokens = synth.build_vocab(corpus[:600_000], V)
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    exp = voc.count_occurrences(corpus, off, max_cp, threads=8)
+    got = _gpu_counts(tokens, (corpus, off), max_cp)
+    bad = np.nonzero(got[0] != exp[0])[0]
+    assert bad.size == 0, (kind, bad[:10], got[0][bad[:10]], exp[0][bad[:10]])
+    assert got[1] == exp[1]
+    assert int(exp[0].sum()) > exp[1] // 2, "the workload is meant to hit often"
+
+
+def test_edge_cases():
+    # empty corpus, empty documents, a document shorter than a token, duplicates, windows at document ends
+    names = [b"ab", b"b", b"ab", "語".encode(), b"abc"]
+    for docs in ([], [b""], [b"", b"ab", b""], [b"a", b"b", b"ab", b"abab"], ["語語a".encode(), b"b" * 5000]):
+        voc = O.OracleVocab(*synth.pack_vocab(names))
+        corpus, off = synth.pack_docs(docs)
+        exp = voc.count_occurrences(corpus, off, 3)
+        got = _gpu_counts(names, (corpus, off), 3)
+        assert np.array_equal(got[0], exp[0]) and got[1] == exp[1], docs

@@ -48,6 +48,7 @@ _SIGNATURES = [
     ("tokscore_score", C.c_int, [C.c_void_p, _u64p, _u64p, _u64p]),
     ("tokscore_score_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("tokscore_score_incremental", C.c_int, [C.c_void_p, _u64p, _u64p, _u64p]),
+    ("tokscore_count_occurrences", C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
     ("tokscore_tokenize", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, C.c_uint64, _u64p]),
     ("tokscore_get_info", C.c_int, [C.c_void_p, C.POINTER(TokscoreInfo)]),
     ("tokscore_last_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
@@ -165,6 +166,15 @@ class Scorer:
 
     def score_async(self, d_out_ptr: int, stream_ptr: int = 0):
         self._check(self._lib.tokscore_score_async(self._h, d_out_ptr, stream_ptr))
+
+    # ExtractCandidates + Trie::AddString on a closed vocabulary (GetTokens.cpp:21-27, Trie.cpp:114-128)
+    def count_occurrences(self, max_cp: int):
+        """-> (counts[V+3] by id, code-point positions): occurrences of every vocabulary string as
+        a window of at most max_cp code points, no lower-casing."""
+        counts = np.zeros(self.V + 3, dtype=np.uint64)
+        pos = C.c_uint64()
+        self._check(self._lib.tokscore_count_occurrences(self._h, max_cp, _p64(counts), C.byref(pos)))
+        return counts, int(pos.value)
 
     # SolutionFile::Tokenize (SolutionFile.cpp:83-100); -1 stands for (size_t)-1
     def tokenize(self, text: bytes):

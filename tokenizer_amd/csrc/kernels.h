@@ -52,4 +52,23 @@ void launch_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t to
 void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,
                       uint32_t *slab, uint32_t slab_blocks, hipStream_t stream);
 
+// slab rows (u32 partials per workgroup, n_cols columns) -> counts[] (u64 atomics)
+void launch_slab_reduce(const uint32_t *slab, uint32_t rows, uint32_t n_cols, unsigned long long *counts,
+                        hipStream_t stream);
+
+// kernels_count.hip -- closed-vocabulary all-occurrence counting (GetTokens.cpp:21-27)
+struct CountPlan {
+	uint32_t halo;      // bytes staged past a tile (longest walk + slack)
+	uint32_t nbins;     // ids counted per pass (LDS bins)
+	uint32_t passes;    // passes over the corpus, one id range each
+	uint32_t lds_slots; // trie slots staged in LDS
+	uint32_t lds_bytes;
+};
+bool plan_count(const TrieDev &T, uint64_t max_len_bytes, uint32_t max_cp, uint32_t n_ids, CountPlan *plan);
+uint32_t count_tiles(uint64_t total_bytes);
+// One pass per id range; every pass writes its id columns of all `blocks` slab rows
+// (n_ids + 1 columns; the last one = code-point positions, written by the first pass).
+void launch_count_all(const TrieDev &T, const CorpusDev &C, const CountPlan &plan, uint32_t max_cp, uint32_t n_ids,
+                      uint32_t blocks, uint32_t *tile_counters, uint32_t *slab, hipStream_t stream);
+
 } // namespace tokscore

@@ -836,6 +836,12 @@ void launch_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t to
 	                   (unsigned long long)total_bytes, Q.cursor, Q.fill, Q.capacity_batches);
 }
 
+void launch_slab_reduce(const uint32_t *slab, uint32_t rows, uint32_t n_cols, unsigned long long *counts,
+                        hipStream_t stream) {
+	hipLaunchKernelGGL(slab_reduce_kernel, dim3((n_cols + 255) / 256, kReduceGroups), dim3(256), 0, stream, slab, rows,
+	                   n_cols, counts);
+}
+
 void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,
                       uint32_t *slab, uint32_t slab_blocks, hipStream_t stream) {
 	const uint32_t n_ids = V + 3;
@@ -851,8 +857,7 @@ void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, 
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		hipLaunchKernelGGL(hist_kernel<false>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab);
 	}
-	hipLaunchKernelGGL(slab_reduce_kernel, dim3((n_ids + 1 + 255) / 256, kReduceGroups), dim3(256), 0, stream, slab,
-	                   slab_blocks, n_ids + 1, counts);
+	launch_slab_reduce(slab, slab_blocks, n_ids + 1, counts, stream);
 }
 
 } // namespace tokscore

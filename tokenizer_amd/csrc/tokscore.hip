@@ -608,6 +608,48 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 	return tokscore_score(c, counts, total_tokens, total_bytes);
 }
 
+int tokscore_count_occurrences(tokscore_ctx *c, uint32_t max_cp, uint64_t *counts, uint64_t *positions) {
+	if (!c || !counts) return fail(c, TOKSCORE_E_ARG, "null output");
+	if (max_cp == 0) return fail(c, TOKSCORE_E_ARG, "max_cp must be at least 1");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	int st = ensure_trie(c);
+	if (st) return st;
+	if (!c->corpus_set) return fail(c, TOKSCORE_E_STATE, "corpus not set");
+	st = ensure_out(c);
+	if (st) return st;
+	const uint32_t n_ids = (uint32_t)c->V + 3;
+	TrieDev T = trie_dev(c);
+	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+	CountPlan plan;
+	if (!plan_count(T, c->packed.max_len, max_cp, n_ids, &plan))
+		return fail(c, TOKSCORE_E_CAPACITY, "tokens too long for the counting kernel's LDS tile");
+	const uint32_t tiles = count_tiles(c->total);
+	const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)c->num_cus, tiles));
+	// a slab cell is an int32 partial of one workgroup
+	if (c->total / blocks >= 0x7FFFFFFFull) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one counting launch");
+	uint32_t *d_slab = nullptr, *d_tiles = nullptr;
+	HIP_TRY(c, hipMalloc((void **)&d_slab, (size_t)blocks * (n_ids + 1) * sizeof(uint32_t)));
+	hipError_t e = hipMalloc((void **)&d_tiles, plan.passes * sizeof(uint32_t));
+	std::vector<uint64_t> host(c->V + 5);
+	do {
+		if (e != hipSuccess) break;
+		if ((e = hipMemsetAsync(d_tiles, 0, plan.passes * sizeof(uint32_t), c->stream)) != hipSuccess) break;
+		if ((e = hipMemsetAsync(c->d_out, 0, (c->V + 5) * sizeof(unsigned long long), c->stream)) != hipSuccess) break;
+		launch_count_all(T, C, plan, max_cp, n_ids, blocks, d_tiles, d_slab, c->stream);
+		launch_slab_reduce(d_slab, blocks, n_ids + 1, c->d_out, c->stream);
+		if ((e = hipGetLastError()) != hipSuccess) break;
+		if ((e = hipMemcpyAsync(host.data(), c->d_out, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
+		e = hipStreamSynchronize(c->stream);
+	} while (0);
+	(void)hipFree(d_slab);
+	if (d_tiles) (void)hipFree(d_tiles);
+	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("count_occurrences: ") + hipGetErrorString(e));
+	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
+	if (positions) *positions = host[c->V + 3];
+	return TOKSCORE_OK;
+}
+
 int tokscore_tokenize(tokscore_ctx *c, const uint8_t *text, uint64_t n, uint64_t *ids_out, uint64_t cap,
                       uint64_t *n_ids) {
 	if (!c || !ids_out || !n_ids || (!text && n)) return fail(c, TOKSCORE_E_ARG, "null buffers");
