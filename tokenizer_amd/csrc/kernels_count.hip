@@ -112,46 +112,76 @@ __global__ void __launch_bounds__(1024) count_all_kernel(TrieDev T, CorpusDev C,
 		__syncthreads();
 		const bool has_bounds = s_bounds != 0;
 
-		// ---- one flat loop per wave: a lane either starts its next position or takes one trie
-		// step of the walk in progress ----
-		uint32_t j = 0, cp = 0, nb = 0, ncp = 0, lim = kNoLim;
-		bool walking = false;
-		while (__builtin_amdgcn_ballot_w64(walking || j < kSlotsPerThread)) {
-			if (walking) {
-				const uint32_t c = tile[cp];
-				const bool lead = is_lead(c);
-				bool stop = cp >= lim || (lead && ncp == max_cp);
-				if (!stop) {
-					ncp += lead ? 1u : 0u;
-					const uint32_t s = nb + c;
-					u32x2 e;
-					if (s < T.lds_slots) e = ltrie[s];
-					else e = gtrie[s];
-					if ((e.x & kSlotKeyMask) == (c | kSlotValid)) {
-						cp++;
-						nb = e.x >> kSlotBaseShift;
-						// a candidate is a string of whole code points: it ends where one starts
-						if (e.y != 0 && (cp >= lim || is_lead(tile[cp]))) {
-							const uint32_t k = e.y - id_lo;
-							if (k < nbins) atomicAdd((uint32_t *)&bins[k], 1u);
-						}
-						stop = nb == 0;
-					} else {
-						stop = true;
+		// ---- one flat loop per wave.  A lane keeps TWO walks in flight (its even and its odd
+		// positions): the positions are independent, so the second walk's byte and slot loads
+		// overlap the first one's -- the loop is bound by the latency of those dependent loads.
+		// A walk that ended picks its next position in the same pass.
+		struct Walk {
+			uint32_t j, cp, nb, ncp, lim;
+			bool on;
+		};
+		Walk w[2];
+#pragma unroll
+		for (int k = 0; k < 2; k++) {
+			w[k].j = (uint32_t)k;
+			w[k].cp = 0;
+			w[k].nb = 0;
+			w[k].ncp = 0;
+			w[k].lim = kNoLim;
+			w[k].on = false;
+		}
+		while (__builtin_amdgcn_ballot_w64(w[0].on || w[1].on || w[0].j < kSlotsPerThread || w[1].j < kSlotsPerThread)) {
+			uint32_t c[2], slot[2];
+			bool go[2];
+			u32x2 e[2];
+			// next position for the walks that are idle
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				if (!w[k].on && w[k].j < kSlotsPerThread) {
+					const uint32_t p = tid + kCountThreads * w[k].j;
+					w[k].j += 2;
+					if (p < hi && is_lead(tile[p])) {
+						positions++;
+						w[k].on = true;
+						w[k].cp = p;
+						w[k].nb = T.root_base;
+						w[k].ncp = 0;
+						w[k].lim = has_bounds ? next_start(bitmap, p, p + halo) : kNoLim;
 					}
 				}
-				walking = !stop;
-			} else if (j < kSlotsPerThread) {
-				const uint32_t p = tid + kCountThreads * j;
-				j++;
-				if (p < hi && is_lead(tile[p])) {
-					positions++;
-					walking = true;
-					cp = p;
-					nb = T.root_base;
-					ncp = 0;
-					lim = has_bounds ? next_start(bitmap, p, p + halo) : kNoLim;
+			}
+			// bytes, then slots, of both walks before either is looked at
+#pragma unroll
+			for (int k = 0; k < 2; k++) c[k] = w[k].on ? (uint32_t)tile[w[k].cp] : 0u;
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				const bool lead = is_lead(c[k]);
+				go[k] = w[k].on && w[k].cp < w[k].lim && !(lead && w[k].ncp == max_cp);
+				w[k].ncp += (go[k] && lead) ? 1u : 0u;
+				slot[k] = w[k].nb + c[k];
+			}
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				e[k] = u32x2{0u, 0u};
+				if (go[k]) {
+					if (slot[k] < T.lds_slots) e[k] = ltrie[slot[k]];
+					else e[k] = gtrie[slot[k]];
 				}
+			}
+#pragma unroll
+			for (int k = 0; k < 2; k++) {
+				bool more = false;
+				if (go[k] && (e[k].x & kSlotKeyMask) == (c[k] | kSlotValid)) {
+					w[k].cp++;
+					w[k].nb = e[k].x >> kSlotBaseShift;
+					// a candidate is a string of whole code points: it ends where one starts
+					if (e[k].y != 0 && (w[k].cp >= w[k].lim || is_lead(tile[w[k].cp]))) {
+						const uint32_t b = e[k].y - id_lo;
+						if (b < nbins) atomicAdd((uint32_t *)&bins[b], 1u);
+					}
+					more = w[k].nb != 0;
+				}
+				w[k].on = more;
 			}
 		}
 	}

@@ -22,7 +22,7 @@ def main():
     mb = float(args[0]) if args else 100.0
     max_cp = int(args[1]) if len(args) > 1 else 10
     src, _ = synth.wiki_like(2_000_000, seed=20201120)
-    tokens = synth.build_vocab(src, 32000)
+    tokens = synth.build_vocab(src, int(os.environ.get("COUNT_VOCAB", "32000")))
     corpus, off = synth.wiki_like(int(mb * 1e6), seed=20201120)
     s = ta.Scorer(0)
     s.set_vocab(*synth.pack_vocab(tokens))
