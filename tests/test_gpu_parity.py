@@ -203,3 +203,58 @@ def test_reference_flow_through_file_mirrors(case):
         assert int(counts[idx]) == v
     assert int(counts.sum()) == sum(exp["counts"].values())
     tkn.close()
+
+
+@pytest.mark.gpu
+def test_incremental_rescore_paths():
+    """tokscore_score_incremental: several toggles per re-score, a token that occurs nearly
+    everywhere (falls back to a full evaluation), a tokenize call between toggle and re-score,
+    re-score without toggles -- always equal to a full evaluation of the toggled vocabulary."""
+    corpus, off = synth.wiki_like(3_000_000, seed=21)
+    tokens = synth.build_vocab(corpus[:600_000], 6000)
+    V = len(tokens)
+
+    def expect(enabled):
+        sub = [t if enabled[k] else b"\x00DISABLED" + str(k).encode() for k, t in enumerate(tokens)]
+        return O.OracleVocab(*synth.pack_vocab(sub)).score(corpus, off, threads=8)
+
+    def same(a, b):
+        return np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        enabled = np.ones(V, dtype=bool)
+        base = s.score()
+        assert same(base, expect(enabled))
+        assert same(s.score(incremental=True), base)              # nothing toggled
+        rng = np.random.default_rng(3)
+        long_tokens = [i for i, t in enumerate(tokens) if len(t) >= 5]
+        for step in range(4):                                       # three toggles per re-score
+            for i in rng.choice(long_tokens, size=3, replace=False):
+                enabled[i] = not enabled[i]
+                s.toggle(int(i), bool(enabled[i]))
+            assert same(s.score(incremental=True), expect(enabled)), step
+        space = tokens.index(b" ") if b" " in tokens else None        # occurs in every chunk
+        if space is not None:
+            enabled[space] = False
+            s.toggle(space, False)
+            assert same(s.score(incremental=True), expect(enabled))
+            enabled[space] = True
+            s.toggle(space, True)
+            assert same(s.score(incremental=True), expect(enabled))
+        i = long_tokens[0]                                          # tokenize in between
+        enabled[i] = not enabled[i]
+        s.toggle(i, bool(enabled[i]))
+        ids = s.tokenize(bytes(corpus[:2000]))
+        sub = [t if enabled[k] else b"\x00DISABLED" + str(k).encode() for k, t in enumerate(tokens)]
+        assert ids == O.OracleVocab(*synth.pack_vocab(sub)).tokenize(bytes(corpus[:2000]))
+        assert same(s.score(incremental=True), expect(enabled))
+        j = long_tokens[1]                                          # toggled there and back before a re-score
+        s.toggle(j, not enabled[j])
+        s.toggle(j, bool(enabled[j]))
+        assert same(s.score(incremental=True), expect(enabled))
+        assert same(s.score(), expect(enabled))
+    finally:
+        s.close()

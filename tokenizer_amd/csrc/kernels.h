@@ -14,6 +14,12 @@ void launch_fixup(const TrieDev &T, const CorpusDev &C, const ChunkState &S, uns
 // token (synced[j] = 1), so that those chunks need no entry repair.
 void launch_snap_chunks(const TrieDev &T, const CorpusDev &C, const uint64_t *begin_in, uint64_t *begin_out,
                         uint32_t *synced, uint32_t nchunks, uint32_t max_len, uint32_t window, hipStream_t stream);
+// Incremental re-score: sel[j] = 1 for every chunk that holds an occurrence of the byte string
+// tok[0 .. len) in the lower-cased corpus (chunks cut every chunk_bytes, each boundary moved
+// forward by less than chunk_bytes); launch_count_sel: n_sel[0] = number of selected chunks.
+void launch_find_token_chunks(const CorpusDev &C, const uint64_t *begin, uint32_t nchunks, uint64_t chunk_bytes,
+                              const uint8_t *tok, uint32_t len, uint32_t *sel, hipStream_t stream);
+void launch_count_sel(const uint32_t *sel, uint32_t nchunks, uint32_t *n_sel, hipStream_t stream);
 void launch_finalize(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, hipStream_t stream);
 void launch_tokenize_one(const TrieDev &T, const uint8_t *text, uint64_t n, unsigned long long *ids, uint64_t cap,
                          unsigned long long *n_ids, hipStream_t stream);
@@ -43,14 +49,16 @@ uint32_t stream_block_bytes(uint32_t wide_ids);
 bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num_cus, TileScanPlan *plan);
 void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S, const StreamDev &Q,
                       const TileScanPlan &plan, const uint64_t *chunk_first_doc, uint64_t max_len,
-                      hipStream_t stream);
+                      hipStream_t stream, const uint32_t *chunk_sel = nullptr);
 // Clears out[0 .. V+5), the stream cursor and fill words in one launch and presets
 // out[0] = out[1] = D (START / END once per document) and out[V+4] = total_bytes.
+// out == nullptr: leave the counts as they are (incremental re-score).
 void launch_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, const StreamDev &Q,
                     hipStream_t stream);
 // counts += histogram of the token stream; out[V+3] += number of tokens counted.
+// flip: subtract what the stream adds and add what it subtracts.
 void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,
-                      uint32_t *slab, uint32_t slab_blocks, hipStream_t stream);
+                      uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip = false);
 
 // slab rows (u32 partials per workgroup, n_cols columns) -> counts[] (u64 atomics)
 void launch_slab_reduce(const uint32_t *slab, uint32_t rows, uint32_t n_cols, unsigned long long *counts,

@@ -189,6 +189,52 @@ __global__ void __launch_bounds__(256) snap_chunks_kernel(TrieDev T, CorpusDev C
 	}
 }
 
+// --- incremental re-score: which chunks can a toggled token change? -------------------
+// Chunk boundaries are token starts of every chain under every subset of enabled tokens
+// (snap_chunks_kernel), so a toggle changes the segmentation of exactly the chunks that hold an
+// occurrence of the token's string (lower-cased text against the token's bytes as they are,
+// SolutionFile.cpp:87-88).  One thread per 16 corpus bytes; the first byte filters, the rest is
+// compared from L1/L2.  A superset is fine (occurrences across document starts are not
+// excluded): re-scoring an unchanged chunk changes nothing.
+__global__ void __launch_bounds__(256) find_token_chunks_kernel(CorpusDev C, const uint64_t *begin, uint32_t nchunks,
+                                                                uint64_t chunk_bytes, const uint8_t *tok, uint32_t len,
+                                                                uint32_t *sel) {
+	const uint64_t nvec = (C.total + 15) / 16;
+	const uint32_t t0 = tok[0];
+	for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t a = v * 16; // the corpus buffer is padded past total: a whole vector is readable
+		const uint4 x = *reinterpret_cast<const uint4 *>(C.bytes + a);
+		const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const uint32_t c = lower8((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
+			if (c != t0) continue;
+			const uint64_t p = a + k;
+			if (p + len > C.total) continue;
+			uint32_t m = 1;
+			while (m < len && lower8(C.bytes[p + m]) == tok[m]) m++;
+			if (m < len) continue;
+			uint64_t j = p / chunk_bytes;
+			if (j >= nchunks) j = nchunks - 1;
+			if (p < begin[j]) j--; // the boundary was moved forward past p
+			if (sel[j] == 0) sel[j] = 1; // (every writer stores the same value)
+		}
+	}
+}
+
+// n_sel[0] = number of selected chunks.  One block.
+__global__ void __launch_bounds__(1024) count_sel_kernel(const uint32_t *sel, uint32_t nchunks, uint32_t *n_sel) {
+	__shared__ uint32_t s_n;
+	if (threadIdx.x == 0) s_n = 0;
+	__syncthreads();
+	uint32_t n = 0;
+	for (uint32_t j = threadIdx.x; j < nchunks; j += blockDim.x) n += sel[j] ? 1u : 0u;
+	for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
+	if ((threadIdx.x & 63) == 0 && n) atomicAdd(&s_n, n);
+	__syncthreads();
+	if (threadIdx.x == 0) n_sel[0] = s_n;
+}
+
 // --- finalize: START/END once per document, totals (main.cpp:40-41) -------------------
 // out = counts[V+3] | total_tokens | total_bytes.  One block.
 __global__ void __launch_bounds__(1024) finalize_kernel(unsigned long long *out, uint32_t V, uint64_t D,
@@ -258,6 +304,19 @@ void launch_snap_chunks(const TrieDev &T, const CorpusDev &C, const uint64_t *be
 	const uint32_t blocks = std::min<uint32_t>((waves + 3) / 4, 4096);
 	hipLaunchKernelGGL(snap_chunks_kernel, dim3(blocks), dim3(256), 0, stream, T, C, begin_in, begin_out, synced, nchunks,
 	                   max_len, window);
+}
+
+void launch_find_token_chunks(const CorpusDev &C, const uint64_t *begin, uint32_t nchunks, uint64_t chunk_bytes,
+                              const uint8_t *tok, uint32_t len, uint32_t *sel, hipStream_t stream) {
+	if (len == 0 || nchunks == 0 || C.total == 0) return;
+	const uint64_t nvec = (C.total + 15) / 16;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>((nvec + 255) / 256, 16384);
+	hipLaunchKernelGGL(find_token_chunks_kernel, dim3(blocks), dim3(256), 0, stream, C, begin, nchunks, chunk_bytes, tok,
+	                   len, sel);
+}
+
+void launch_count_sel(const uint32_t *sel, uint32_t nchunks, uint32_t *n_sel, hipStream_t stream) {
+	hipLaunchKernelGGL(count_sel_kernel, dim3(1), dim3(1024), 0, stream, sel, nchunks, n_sel);
 }
 
 void launch_finalize(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, hipStream_t stream) {

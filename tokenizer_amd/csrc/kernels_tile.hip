@@ -365,7 +365,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C, ChunkState S, StreamDev Qd,
                                                          const uint64_t *chunk_first_doc, uint32_t seg_bytes,
                                                          uint32_t halo_bytes, uint32_t max_len, uint32_t wave_lds_bytes,
-                                                         uint64_t readable_end) {
+                                                         uint64_t readable_end, const uint32_t *chunk_sel) {
 	using Q = QTraits<WIDE>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const uint32_t lane = threadIdx.x & 63;
@@ -418,6 +418,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 		if (lane == 0) j = atomicAdd(&Qd.cursor[kQueueHeadWord + queue * kQueueHeadStride], 1u);
 		j = __builtin_amdgcn_readfirstlane(j) * kWorkQueues + queue;
 		if (j >= S.nchunks) break;
+		if (chunk_sel && chunk_sel[j] == 0) continue; // incremental re-score: only the selected chunks
 		const uint64_t begin = S.begin[j];
 		const uint64_t end = S.begin[j + 1];
 		uint64_t di = chunk_first_doc[j]; // index of the first document offset >= begin
@@ -671,7 +672,8 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 // consumes its share of the stream (16-byte vectors, null entries skipped), then stores the
 // bins to its slab row.
 template <bool WIDE>
-__global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids, uint32_t range_ids, uint32_t *slab) {
+__global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids, uint32_t range_ids, uint32_t *slab,
+                                                    uint32_t flip) {
 	using Q = QTraits<WIDE>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	uint32_t *bins = reinterpret_cast<uint32_t *>(smem);
@@ -701,7 +703,7 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 			if (WIDE) {
 				const uint32_t e = wds[k];
 				const uint32_t id = e & 0x7FFFFFFFu;
-				const int sgn = (e & Q::neg) ? -1 : 1;
+				const int sgn = (((e & Q::neg) != 0) != (flip != 0)) ? -1 : 1;
 				total += sgn;
 				if (id >= lo && id < hi) atomicAdd(&bins[id - lo], (uint32_t)sgn);
 			} else {
@@ -710,7 +712,7 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 					const uint32_t e = (wds[k] >> (16 * h)) & 0xFFFFu;
 					const uint32_t id = e & 0x7FFFu;
 					if (id == Q::null_entry) continue;
-					const int sgn = (e & Q::neg) ? -1 : 1;
+					const int sgn = (((e & Q::neg) != 0) != (flip != 0)) ? -1 : 1;
 					total += sgn;
 					if (id >= lo && id < hi) atomicAdd(&bins[id - lo], (uint32_t)sgn);
 				}
@@ -748,7 +750,8 @@ __global__ void __launch_bounds__(256) prepare_kernel(unsigned long long *out, u
                                                       uint32_t n_fill) {
 	const uint32_t n = gridDim.x * blockDim.x;
 	const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
-	for (uint32_t i = i0; i < V + 5; i += n) out[i] = i < 2 ? D : (i == V + 4 ? total_bytes : 0ull);
+	if (out)
+		for (uint32_t i = i0; i < V + 5; i += n) out[i] = i < 2 ? D : (i == V + 4 ? total_bytes : 0ull);
 	for (uint32_t i = i0; i < kCursorWords; i += n) cursor[i] = 0;
 	for (uint32_t i = i0; i < n_fill; i += n) fill[i] = 0;
 }
@@ -809,7 +812,7 @@ bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num
 
 void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S, const StreamDev &Q,
                       const TileScanPlan &plan, const uint64_t *chunk_first_doc, uint64_t max_len,
-                      hipStream_t stream) {
+                      hipStream_t stream, const uint32_t *chunk_sel) {
 	const uint32_t halo = (uint32_t)((max_len + 15) & ~15ull);
 	const uint32_t wave_bytes = (plan.lds_bytes - plan.lds_slots * 8) / plan.waves_per_block;
 	const uint64_t readable_end = (C.total + 256) & ~15ull;
@@ -820,13 +823,13 @@ void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S,
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
 		hipLaunchKernelGGL(scan_tile_kernel<true>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes,
 		                   stream, Tl, C, S, Q, chunk_first_doc, plan.seg_bytes, halo, (uint32_t)max_len, wave_bytes,
-		                   readable_end);
+		                   readable_end, chunk_sel);
 	} else {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_tile_kernel<false>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
 		hipLaunchKernelGGL(scan_tile_kernel<false>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes,
 		                   stream, Tl, C, S, Q, chunk_first_doc, plan.seg_bytes, halo, (uint32_t)max_len, wave_bytes,
-		                   readable_end);
+		                   readable_end, chunk_sel);
 	}
 }
 
@@ -843,7 +846,7 @@ void launch_slab_reduce(const uint32_t *slab, uint32_t rows, uint32_t n_cols, un
 }
 
 void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,
-                      uint32_t *slab, uint32_t slab_blocks, hipStream_t stream) {
+                      uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip) {
 	const uint32_t n_ids = V + 3;
 	const uint32_t range = std::min<uint32_t>(n_ids, 32768);
 	const uint32_t ranges = (n_ids + range - 1) / range;
@@ -851,11 +854,13 @@ void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, 
 	if (plan.wide_ids) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_kernel<true>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(hist_kernel<true>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab);
+		hipLaunchKernelGGL(hist_kernel<true>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab,
+		                   flip ? 1u : 0u);
 	} else {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_kernel<false>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(hist_kernel<false>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab);
+		hipLaunchKernelGGL(hist_kernel<false>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab,
+		                   flip ? 1u : 0u);
 	}
 	launch_slab_reduce(slab, slab_blocks, n_ids + 1, counts, stream);
 }

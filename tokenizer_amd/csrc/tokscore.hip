@@ -56,6 +56,16 @@ struct tokscore_ctx {
 	uint64_t *d_slots = nullptr;
 	uint64_t d_slots_cap = 0;
 	uint64_t V = 0;
+	// the token strings (incremental re-score looks for the toggled tokens' occurrences)
+	std::vector<uint8_t> h_vocab_bytes;
+	std::vector<uint64_t> h_vocab_off;
+	uint8_t *d_vocab_bytes = nullptr;
+	bool d_vocab_valid = false;
+	// toggles since the device trie was last brought up to date: (token, slot whose id changed)
+	std::vector<std::pair<uint64_t, int64_t>> pending;
+	// d_out holds the result of the last synchronous evaluation of the resident corpus under
+	// the device trie's state (what an incremental re-score starts from)
+	bool state_valid = false;
 
 	// corpus
 	bool corpus_set = false;
@@ -80,6 +90,8 @@ struct tokscore_ctx {
 	uint32_t *d_chunk_state = nullptr; // entry | exit_a | exit_b
 	uint32_t nchunks = 0;
 	uint32_t unsynced = 0; // chunks whose entry is speculated (not at a guaranteed token start)
+	bool uniform_chunks = false; // boundaries at multiples of chunk_bytes, each moved forward by < chunk_bytes
+	uint32_t *d_sel = nullptr;   // [nchunks] chunk selection of an incremental re-score, + 1 word: their number
 	void *d_stream = nullptr;
 	uint32_t stream_cap_batches = 0;
 	uint32_t *d_fill = nullptr;
@@ -132,6 +144,8 @@ void free_plan(tokscore_ctx *c) {
 	if (c->d_cursor) (void)hipFree(c->d_cursor);
 	if (c->d_fill) (void)hipFree(c->d_fill);
 	c->d_fill = nullptr;
+	if (c->d_sel) (void)hipFree(c->d_sel);
+	c->d_sel = nullptr;
 	if (c->d_slab) (void)hipFree(c->d_slab);
 	c->d_chunk_begin = nullptr;
 	c->d_chunk_state = nullptr;
@@ -202,7 +216,30 @@ int ensure_trie(tokscore_ctx *c) {
 		                          c->stream));
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		c->device_trie_valid = true;
+		c->pending.clear();
+		c->state_valid = false;
 	}
+	if (!c->d_vocab_valid) {
+		if (c->d_vocab_bytes) (void)hipFree(c->d_vocab_bytes);
+		c->d_vocab_bytes = nullptr;
+		HIP_TRY(c, hipMalloc((void **)&c->d_vocab_bytes, c->h_vocab_bytes.size() + 16));
+		if (!c->h_vocab_bytes.empty())
+			HIP_TRY(c, hipMemcpy(c->d_vocab_bytes, c->h_vocab_bytes.data(), c->h_vocab_bytes.size(), hipMemcpyHostToDevice));
+		c->d_vocab_valid = true;
+	}
+	return TOKSCORE_OK;
+}
+
+// Bring the device trie up to date with the host image: one 8-byte slot per pending toggle,
+// enqueued on s (in order after whatever still reads the old state there).
+int apply_pending(tokscore_ctx *c, hipStream_t s) {
+	if (c->pending.empty()) return TOKSCORE_OK;
+	if (c->device_trie_valid) {
+		for (const auto &pd : c->pending)
+			HIP_TRY(c, hipMemcpyAsync(c->d_slots + pd.second, &c->packed.slots[pd.second], sizeof(uint64_t),
+			                          hipMemcpyHostToDevice, s));
+	}
+	c->pending.clear();
 	return TOKSCORE_OK;
 }
 
@@ -231,6 +268,7 @@ int ensure_plan(tokscore_ctx *c) {
 	if (c->chunk_bytes < 64) c->chunk_bytes = 64;
 	if (c->chunk_bytes < 4 * c->packed.max_len) c->chunk_bytes = 4 * c->packed.max_len;
 	build_chunks(c, c->chunk_bytes, snap);
+	c->uniform_chunks = snap;
 	c->nchunks = (uint32_t)(c->h_chunk_begin.size() - 1);
 	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_begin, c->h_chunk_begin.size() * sizeof(uint64_t)));
 	HIP_TRY(c, hipMemcpy(c->d_chunk_begin, c->h_chunk_begin.data(), c->h_chunk_begin.size() * sizeof(uint64_t),
@@ -274,6 +312,7 @@ int ensure_plan(tokscore_ctx *c) {
 		HIP_TRY(c, hipMemcpy(c->d_chunk_first_doc, first.data(), first.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, kCursorWords * sizeof(uint32_t)));
+	HIP_TRY(c, hipMalloc((void **)&c->d_sel, ((size_t)c->nchunks + 1) * sizeof(uint32_t)));
 	if (c->scan_path == 1) {
 		// Token stream: one entry per emitted token plus the repair rounds' +/- entries, in
 		// log blocks that are partly empty.  3 entries per corpus byte is far above anything
@@ -312,6 +351,9 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	if (!c->corpus_set) return fail(c, TOKSCORE_E_STATE, "corpus not set");
 	st = ensure_plan(c);
 	if (st) return st;
+	st = apply_pending(c, s);
+	if (st) return st;
+	c->state_valid = false;
 	TrieDev T = trie_dev(c);
 	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
 	ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
@@ -441,6 +483,7 @@ void tokscore_destroy(tokscore_ctx *c) {
 		free_plan(c);
 		free_corpus(c);
 		if (c->d_slots) (void)hipFree(c->d_slots);
+		if (c->d_vocab_bytes) (void)hipFree(c->d_vocab_bytes);
 		if (c->d_out) (void)hipFree(c->d_out);
 		for (auto &set : c->ring)
 			for (auto &e : set)
@@ -462,7 +505,13 @@ int tokscore_set_vocab(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *of
 	c->packed_valid = false;
 	c->device_trie_valid = false;
 	c->plan_valid = false;
+	c->pending.clear();
+	c->state_valid = false;
+	c->d_vocab_valid = false;
 	if (!c->trie.Build(bytes ? bytes : &kEmpty, off, V, &e)) return fail(c, TOKSCORE_E_VOCAB, e);
+	c->h_vocab_off.resize(V + 1);
+	for (uint64_t i = 0; i <= V; i++) c->h_vocab_off[i] = off[i] - off[0];
+	c->h_vocab_bytes.assign(bytes ? bytes + off[0] : &kEmpty, bytes ? bytes + off[V] : &kEmpty);
 	c->V = V;
 	c->vocab_set = true;
 	c->sample_used = false;
@@ -486,12 +535,9 @@ int tokscore_toggle(tokscore_ctx *c, uint64_t token_index, int enable) {
 	}
 	uint64_t entry = 0;
 	const int64_t slot = c->trie.Toggle(token_index, enable != 0, &c->packed, &entry);
-	if (slot >= 0 && !c->hostonly && c->device_trie_valid) {
-		(void)hipSetDevice(c->device);
-		HIP_TRY(c, hipMemcpyAsync(c->d_slots + slot, &c->packed.slots[slot], sizeof(uint64_t), hipMemcpyHostToDevice,
-		                          c->stream));
-		HIP_TRY(c, hipStreamSynchronize(c->stream));
-	}
+	// The device copy is patched by the next evaluation (apply_pending): an incremental
+	// re-score first takes back what the OLD trie counted in the chunks the token occurs in.
+	if (slot >= 0 && !c->hostonly && c->device_trie_valid) c->pending.emplace_back(token_index, slot);
 	return TOKSCORE_OK;
 }
 
@@ -513,6 +559,7 @@ int tokscore_set_corpus(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *o
 	(void)hipSetDevice(c->device);
 	free_plan(c);
 	free_corpus(c);
+	c->state_valid = false;
 	int st = adopt_offsets(c, off, D);
 	if (st) return st;
 	if (c->total && !bytes) return fail(c, TOKSCORE_E_ARG, "null corpus bytes");
@@ -547,6 +594,7 @@ int tokscore_set_corpus_device(tokscore_ctx *c, const void *d_bytes, const void 
 	(void)hipSetDevice(c->device);
 	free_plan(c);
 	free_corpus(c);
+	c->state_valid = false;
 	std::vector<uint64_t> off(D + 1);
 	HIP_TRY(c, hipMemcpy(off.data(), d_off, (D + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost));
 	if (off[0] != 0 || off[D] != total_bytes) return fail(c, TOKSCORE_E_ARG, "device offsets must run from 0 to total_bytes");
@@ -596,6 +644,7 @@ int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, ui
 		return tokscore_score(c, counts, total_tokens, total_bytes);
 	}
 	if (st) return st;
+	c->state_valid = true; // d_out = this evaluation, the device trie = the vocabulary it used
 	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
 	if (total_tokens) *total_tokens = host[c->V + 3];
 	if (total_bytes) *total_bytes = host[c->V + 4];
@@ -603,9 +652,83 @@ int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, ui
 }
 
 int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, uint64_t *total_bytes) {
-	// Toggles patch the resident trie in place (one 8-byte slot each), so a re-score is
-	// a plain evaluation without any rebuild or re-upload.
-	return tokscore_score(c, counts, total_tokens, total_bytes);
+	// Re-score after toggles.  Chunk boundaries are token starts under every subset of enabled
+	// tokens, so only the chunks that hold an occurrence of a toggled token's string can change:
+	// those are scanned twice -- with the trie as it was (their old contribution, subtracted) and,
+	// after the pending slot patches, as it is (added) -- on top of the counts the last
+	// evaluation left in d_out.  Same result as tokscore_score, bit for bit; anything that does
+	// not fit the fast path (no previous evaluation, fallback scan path, speculated boundaries,
+	// many toggles, a token that occurs in a third of the chunks) is a plain full evaluation.
+	if (!c || !counts) return fail(c, TOKSCORE_E_ARG, "null output");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	const bool eligible = c->state_valid && c->plan_valid && c->packed_valid && c->device_trie_valid && c->d_vocab_valid &&
+	                      c->scan_path == 1 && c->unsynced == 0 && c->uniform_chunks && c->pending.size() <= 8 &&
+	                      !env_u64("TOKSCORE_NOINCR", 0);
+	if (!eligible) return tokscore_score(c, counts, total_tokens, total_bytes);
+	hipStream_t s = c->stream;
+	std::vector<uint64_t> host(c->V + 5);
+	uint32_t nsel = 0;
+	if (!c->pending.empty()) {
+		TrieDev T = trie_dev(c);
+		CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+		ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
+		             c->d_chunk_state + 2 * (size_t)(c->nchunks + 1), c->nchunks};
+		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
+		c->ev = c->ring[c->calls % tokscore_ctx::kRing];
+		c->calls++;
+		HIP_TRY(c, hipEventRecord(c->ev[0], s));
+		HIP_TRY(c, hipMemsetAsync(c->d_sel, 0, ((size_t)c->nchunks + 1) * sizeof(uint32_t), s));
+		for (size_t k = 0; k < c->pending.size(); k++) {
+			const uint64_t tok = c->pending[k].first;
+			bool seen = false;
+			for (size_t m = 0; m < k; m++) seen = seen || c->pending[m].first == tok;
+			const uint64_t len = c->h_vocab_off[tok + 1] - c->h_vocab_off[tok];
+			if (seen || len == 0) continue;
+			launch_find_token_chunks(C, c->d_chunk_begin, c->nchunks, c->chunk_bytes, c->d_vocab_bytes + c->h_vocab_off[tok],
+			                         (uint32_t)len, c->d_sel, s);
+		}
+		launch_count_sel(c->d_sel, c->nchunks, c->d_sel + c->nchunks, s);
+		HIP_TRY(c, hipMemcpyAsync(&nsel, c->d_sel + c->nchunks, sizeof nsel, hipMemcpyDeviceToHost, s));
+		HIP_TRY(c, hipStreamSynchronize(s));
+		if (nsel > c->nchunks / 3) return tokscore_score(c, counts, total_tokens, total_bytes);
+		HIP_TRY(c, hipEventRecord(c->ev[1], s));
+		if (nsel) {
+			launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s);
+			launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s, c->d_sel);
+			launch_histogram(Q, c->tile, (uint32_t)c->V, c->d_out, c->d_slab, c->slab_blocks, s, /*flip=*/true);
+		}
+		HIP_TRY(c, hipEventRecord(c->ev[2], s));
+		c->state_valid = false; // until the second half is in
+		int st = apply_pending(c, s);
+		if (st) return st;
+		HIP_TRY(c, hipEventRecord(c->ev[3], s));
+		if (nsel) {
+			launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s);
+			launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s, c->d_sel);
+			launch_histogram(Q, c->tile, (uint32_t)c->V, c->d_out, c->d_slab, c->slab_blocks, s, /*flip=*/false);
+		}
+		HIP_TRY(c, hipEventRecord(c->ev[4], s));
+		HIP_TRY(c, hipGetLastError());
+		c->timing_pending = true;
+	}
+	HIP_TRY(c, hipMemcpyAsync(host.data(), c->d_out, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+	HIP_TRY(c, hipStreamSynchronize(s));
+	if (nsel) {
+		// (two passes share the overflow flag: prepare clears it, so this sees the second one;
+		// a partial scan holds at most a third of what a full one is sized for)
+		int st = check_overflow(c);
+		if (st) {
+			c->force_generic = true;
+			c->plan_valid = false;
+			return tokscore_score(c, counts, total_tokens, total_bytes);
+		}
+	}
+	c->state_valid = true;
+	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
+	if (total_tokens) *total_tokens = host[c->V + 3];
+	if (total_bytes) *total_bytes = host[c->V + 4];
+	return TOKSCORE_OK;
 }
 
 int tokscore_count_occurrences(tokscore_ctx *c, uint32_t max_cp, uint64_t *counts, uint64_t *positions) {
@@ -618,6 +741,9 @@ int tokscore_count_occurrences(tokscore_ctx *c, uint32_t max_cp, uint64_t *count
 	if (!c->corpus_set) return fail(c, TOKSCORE_E_STATE, "corpus not set");
 	st = ensure_out(c);
 	if (st) return st;
+	st = apply_pending(c, c->stream);
+	if (st) return st;
+	c->state_valid = false; // d_out is reused below
 	const uint32_t n_ids = (uint32_t)c->V + 3;
 	TrieDev T = trie_dev(c);
 	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
@@ -657,6 +783,11 @@ int tokscore_tokenize(tokscore_ctx *c, const uint8_t *text, uint64_t n, uint64_t
 	(void)hipSetDevice(c->device);
 	int st = ensure_trie(c);
 	if (st) return st;
+	if (!c->pending.empty()) {
+		st = apply_pending(c, c->stream);
+		if (st) return st;
+		c->state_valid = false; // the device trie moved on without the counts
+	}
 	uint8_t *d_text = nullptr;
 	unsigned long long *d_ids = nullptr;
 	const uint64_t need = n + 2;
