@@ -141,7 +141,8 @@ typedef struct {
 	uint32_t slot_bits;       /* packed slot = label:8 | valid:1 | base:slot_bits, then id:id_bits */
 	uint32_t id_bits;
 	uint32_t scan_path;       /* 1 = LDS tile scan kernel, 0 = generic global-memory scan */
-	uint32_t reserved;
+	uint32_t rescored_chunks; /* chunks re-scanned by the last tokscore_score_incremental;
+	                           * UINT32_MAX when it ran (or fell back to) a full evaluation */
 } tokscore_info;
 int tokscore_get_info(tokscore_ctx *ctx, tokscore_info *info);
 

@@ -28,7 +28,7 @@ class TokscoreInfo(C.Structure):
     _fields_ = [("vocab_size", C.c_uint64), ("max_len", C.c_uint64), ("trie_nodes", C.c_uint64),
                 ("trie_slots", C.c_uint64), ("trie_lds_slots", C.c_uint64), ("corpus_bytes", C.c_uint64),
                 ("corpus_docs", C.c_uint64), ("chunks", C.c_uint64), ("slot_bits", C.c_uint32),
-                ("id_bits", C.c_uint32), ("scan_path", C.c_uint32), ("reserved", C.c_uint32)]
+                ("id_bits", C.c_uint32), ("scan_path", C.c_uint32), ("rescored_chunks", C.c_uint32)]
 
 
 # every symbol include/tokscore.h declares: (name, restype, argtypes)

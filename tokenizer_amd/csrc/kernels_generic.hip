@@ -206,18 +206,26 @@ __global__ void __launch_bounds__(256) find_token_chunks_kernel(CorpusDev C, con
 		const uint4 x = *reinterpret_cast<const uint4 *>(C.bytes + a);
 		const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-		for (int k = 0; k < 16; k++) {
-			const uint32_t c = lower8((w[k >> 2] >> (8 * (k & 3))) & 0xFFu);
-			if (c != t0) continue;
-			const uint64_t p = a + k;
-			if (p + len > C.total) continue;
-			uint32_t m = 1;
-			while (m < len && lower8(C.bytes[p + m]) == tok[m]) m++;
-			if (m < len) continue;
-			uint64_t j = p / chunk_bytes;
-			if (j >= nchunks) j = nchunks - 1;
-			if (p < begin[j]) j--; // the boundary was moved forward past p
-			if (sel[j] == 0) sel[j] = 1; // (every writer stores the same value)
+		for (int q = 0; q < 4; q++) {
+			// bytes of this dword equal to the token's first byte, four at a time: lower-case
+			// (A-Z only), xor with the byte broadcast, exact zero-byte test
+			const uint32_t low7 = w[q] & 0x7F7F7F7Fu;
+			const uint32_t up = (low7 + 0x3F3F3F3Fu) & ~(low7 + 0x25252525u) & ~w[q] & 0x80808080u;
+			const uint32_t y = (w[q] | (up >> 2)) ^ (t0 * 0x01010101u);
+			uint32_t hit = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); // 0x80 where a byte of y is zero
+			while (hit) {
+				const uint32_t k = (uint32_t)q * 4 + ((uint32_t)__builtin_ctz(hit) >> 3);
+				hit &= hit - 1;
+				const uint64_t p = a + k;
+				if (p + len > C.total) continue;
+				uint32_t m = 1;
+				while (m < len && lower8(C.bytes[p + m]) == tok[m]) m++;
+				if (m < len) continue;
+				uint64_t j = p / chunk_bytes;
+				if (j >= nchunks) j = nchunks - 1;
+				if (p < begin[j]) j--; // the boundary was moved forward past p
+				if (sel[j] == 0) sel[j] = 1; // (every writer stores the same value)
+			}
 		}
 	}
 }

@@ -66,6 +66,7 @@ struct tokscore_ctx {
 	// d_out holds the result of the last synchronous evaluation of the resident corpus under
 	// the device trie's state (what an incremental re-score starts from)
 	bool state_valid = false;
+	uint32_t rescored_chunks = 0xFFFFFFFFu; // by the last incremental re-score (UINT32_MAX: full evaluation)
 
 	// corpus
 	bool corpus_set = false;
@@ -645,6 +646,7 @@ int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, ui
 	}
 	if (st) return st;
 	c->state_valid = true; // d_out = this evaluation, the device trie = the vocabulary it used
+	c->rescored_chunks = 0xFFFFFFFFu;
 	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
 	if (total_tokens) *total_tokens = host[c->V + 3];
 	if (total_bytes) *total_bytes = host[c->V + 4];
@@ -691,7 +693,10 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		launch_count_sel(c->d_sel, c->nchunks, c->d_sel + c->nchunks, s);
 		HIP_TRY(c, hipMemcpyAsync(&nsel, c->d_sel + c->nchunks, sizeof nsel, hipMemcpyDeviceToHost, s));
 		HIP_TRY(c, hipStreamSynchronize(s));
-		if (nsel > c->nchunks / 3) return tokscore_score(c, counts, total_tokens, total_bytes);
+		if (nsel > c->nchunks / 3) {
+			c->calls--; // this call's event set goes to the full evaluation
+			return tokscore_score(c, counts, total_tokens, total_bytes);
+		}
 		HIP_TRY(c, hipEventRecord(c->ev[1], s));
 		if (nsel) {
 			launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s);
@@ -725,6 +730,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		}
 	}
 	c->state_valid = true;
+	c->rescored_chunks = nsel;
 	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
 	if (total_tokens) *total_tokens = host[c->V + 3];
 	if (total_bytes) *total_bytes = host[c->V + 4];
@@ -835,6 +841,7 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 		info->scan_path = (uint32_t)c->scan_path;
 		info->trie_lds_slots = c->tile.lds_slots;
 	}
+	info->rescored_chunks = c->rescored_chunks;
 	return TOKSCORE_OK;
 }
 
