@@ -206,12 +206,15 @@ def test_reference_flow_through_file_mirrors(case):
 
 
 @pytest.mark.gpu
-def test_incremental_rescore_paths():
+@pytest.mark.parametrize("index_mb", ["2048", "0"])  # with the occurrence index / by searching the corpus
+def test_incremental_rescore_paths(index_mb):
     """tokscore_score_incremental: several toggles per re-score, a token that occurs nearly
     everywhere (falls back to a full evaluation), a tokenize call between toggle and re-score,
     re-score without toggles -- always equal to a full evaluation of the toggled vocabulary."""
     corpus, off = synth.wiki_like(3_000_000, seed=21)
     tokens = synth.build_vocab(corpus[:600_000], 6000)
+    tokens.append(bytes(corpus[1_234_560:1_234_572]).lower())   # a string that occurs in very few chunks
+    assert tokens[-1] not in tokens[:-1]
     V = len(tokens)
 
     def expect(enabled):
@@ -221,6 +224,8 @@ def test_incremental_rescore_paths():
     def same(a, b):
         return np.array_equal(a[0], b[0]) and a[1:] == b[1:]
 
+    old_env = os.environ.get("TOKSCORE_INDEX_MB")
+    os.environ["TOKSCORE_INDEX_MB"] = index_mb
     s = ta.Scorer(0)
     try:
         s.set_vocab(*synth.pack_vocab(tokens))
@@ -229,6 +234,11 @@ def test_incremental_rescore_paths():
         base = s.score()
         assert same(base, expect(enabled))
         assert same(s.score(incremental=True), base)              # nothing toggled
+        rare = V - 1
+        enabled[rare] = False
+        s.toggle(rare, False)
+        assert same(s.score(incremental=True), expect(enabled))
+        assert s.info().rescored_chunks < s.info().chunks, "the fast path was expected to be taken"
         rng = np.random.default_rng(3)
         long_tokens = [i for i, t in enumerate(tokens) if len(t) >= 5]
         for step in range(4):                                       # three toggles per re-score
@@ -258,3 +268,7 @@ def test_incremental_rescore_paths():
         assert same(s.score(), expect(enabled))
     finally:
         s.close()
+        if old_env is None:
+            os.environ.pop("TOKSCORE_INDEX_MB", None)
+        else:
+            os.environ["TOKSCORE_INDEX_MB"] = old_env

@@ -14,12 +14,20 @@ void launch_fixup(const TrieDev &T, const CorpusDev &C, const ChunkState &S, uns
 // token (synced[j] = 1), so that those chunks need no entry repair.
 void launch_snap_chunks(const TrieDev &T, const CorpusDev &C, const uint64_t *begin_in, uint64_t *begin_out,
                         uint32_t *synced, uint32_t nchunks, uint32_t max_len, uint32_t window, hipStream_t stream);
-// Incremental re-score: sel[j] = 1 for every chunk that holds an occurrence of the byte string
+// Incremental re-score: bit j of sel = 1 for every chunk that holds an occurrence of the byte string
 // tok[0 .. len) in the lower-cased corpus (chunks cut every chunk_bytes, each boundary moved
 // forward by less than chunk_bytes); launch_count_sel: n_sel[0] = number of selected chunks.
 void launch_find_token_chunks(const CorpusDev &C, const uint64_t *begin, uint32_t nchunks, uint64_t chunk_bytes,
                               const uint8_t *tok, uint32_t len, uint32_t *sel, hipStream_t stream);
 void launch_count_sel(const uint32_t *sel, uint32_t nchunks, uint32_t *n_sel, hipStream_t stream);
+// Occurrence index, built once per plan: index[row][chunk bit] = string `row` occurs in the chunk
+// (slot_row[t] = row of the string that ends at slot t, or -1); row_chunks[row] = its chunk count.
+// launch_or_rows: sel = OR of up to 8 rows.  (sel is a chunk bitmap, (nchunks + 31) / 32 words.)
+void launch_index_all(const TrieDev &T, const CorpusDev &C, const int32_t *slot_row, const uint64_t *begin,
+                      uint32_t nchunks, uint64_t chunk_bytes, uint32_t rows, uint32_t *index, uint32_t *row_chunks,
+                      hipStream_t stream);
+void launch_or_rows(const uint32_t *index, const uint32_t *rows, uint32_t n, uint32_t nchunks, uint32_t *sel,
+                    hipStream_t stream);
 void launch_finalize(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, hipStream_t stream);
 void launch_tokenize_one(const TrieDev &T, const uint8_t *text, uint64_t n, unsigned long long *ids, uint64_t cap,
                          unsigned long long *n_ids, hipStream_t stream);

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) snap_chunks_kernel(TrieDev T, CorpusDev C
 // excluded): re-scoring an unchanged chunk changes nothing.
 __global__ void __launch_bounds__(256) find_token_chunks_kernel(CorpusDev C, const uint64_t *begin, uint32_t nchunks,
                                                                 uint64_t chunk_bytes, const uint8_t *tok, uint32_t len,
-                                                                uint32_t *sel) {
+                                                                uint32_t *sel) { // sel: one bit per chunk
 	const uint64_t nvec = (C.total + 15) / 16;
 	const uint32_t t0 = tok[0];
 	for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (uint64_t)gridDim.x * blockDim.x) {
@@ -224,23 +224,79 @@ __global__ void __launch_bounds__(256) find_token_chunks_kernel(CorpusDev C, con
 				uint64_t j = p / chunk_bytes;
 				if (j >= nchunks) j = nchunks - 1;
 				if (p < begin[j]) j--; // the boundary was moved forward past p
-				if (sel[j] == 0) sel[j] = 1; // (every writer stores the same value)
+				const uint32_t bit = 1u << (j & 31);
+				if (!(sel[j >> 5] & bit)) atomicOr(&sel[j >> 5], bit);
 			}
 		}
 	}
 }
 
-// n_sel[0] = number of selected chunks.  One block.
-__global__ void __launch_bounds__(1024) count_sel_kernel(const uint32_t *sel, uint32_t nchunks, uint32_t *n_sel) {
+// n_sel[0] = number of selected chunks (bits set in sel[0 .. words)).  One block.
+__global__ void __launch_bounds__(1024) count_sel_kernel(const uint32_t *sel, uint32_t words, uint32_t *n_sel) {
 	__shared__ uint32_t s_n;
 	if (threadIdx.x == 0) s_n = 0;
 	__syncthreads();
 	uint32_t n = 0;
-	for (uint32_t j = threadIdx.x; j < nchunks; j += blockDim.x) n += sel[j] ? 1u : 0u;
+	for (uint32_t j = threadIdx.x; j < words; j += blockDim.x) n += (uint32_t)__builtin_popcount(sel[j]);
 	for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
 	if ((threadIdx.x & 63) == 0 && n) atomicAdd(&s_n, n);
 	__syncthreads();
 	if (threadIdx.x == 0) n_sel[0] = s_n;
+}
+
+// --- occurrence index: which chunks does each vocabulary string occur in? ---------------
+// One bit per (string, chunk), built once per plan so that an incremental re-score needs no
+// search: from every byte position of the lower-cased corpus walk the trie and mark every
+// string passed (whatever is enabled: slot_row maps a slot to its string's row).  Document
+// starts are not honoured -- a superset of the chunks a toggle can change is all that is needed.
+__global__ void __launch_bounds__(256) index_all_kernel(TrieDev T, CorpusDev C, const int32_t *slot_row,
+                                                        const uint64_t *begin, uint32_t nchunks, uint64_t chunk_bytes,
+                                                        uint32_t words_per_row, uint32_t *index) {
+	for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < C.total; p += (uint64_t)gridDim.x * blockDim.x) {
+		uint64_t j = p / chunk_bytes;
+		if (j >= nchunks) j = nchunks - 1;
+		if (p < begin[j]) j--;
+		const uint32_t word = (uint32_t)(j >> 5), bit = 1u << (j & 31);
+		uint32_t nb = T.root_base;
+		for (uint64_t q = p; nb != 0 && q < C.total; q++) {
+			const uint32_t c = lower8(C.bytes[q]);
+			const uint32_t t = nb + c;
+			const uint2 e = T.slots[t];
+			if ((e.x & kSlotKeyMask) != (c | kSlotValid)) break;
+			nb = e.x >> kSlotBaseShift;
+			const int32_t row = slot_row[t];
+			if (row >= 0) {
+				uint32_t *w = index + (size_t)row * words_per_row + word;
+				if (!(*w & bit)) atomicOr(w, bit);
+			}
+		}
+	}
+}
+
+// row_chunks[r] = number of chunks string r occurs in
+__global__ void __launch_bounds__(256) index_row_counts_kernel(const uint32_t *index, uint32_t rows, uint32_t words_per_row,
+                                                               uint32_t *row_chunks) {
+	const uint32_t r = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; // one wave per row
+	const uint32_t lane = threadIdx.x & 63;
+	if (r >= rows) return;
+	uint32_t n = 0;
+	for (uint32_t w = lane; w < words_per_row; w += 64) n += (uint32_t)__builtin_popcount(index[(size_t)r * words_per_row + w]);
+	for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
+	if (lane == 0) row_chunks[r] = n;
+}
+
+// sel = OR of the listed index rows
+struct RowList {
+	uint32_t n;
+	uint32_t row[8];
+};
+__global__ void __launch_bounds__(256) or_rows_kernel(const uint32_t *index, RowList rows, uint32_t words_per_row,
+                                                      uint32_t *sel) {
+	const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= words_per_row) return;
+	uint32_t v = 0;
+	for (uint32_t k = 0; k < rows.n; k++) v |= index[(size_t)rows.row[k] * words_per_row + w];
+	sel[w] = v;
 }
 
 // --- finalize: START/END once per document, totals (main.cpp:40-41) -------------------
@@ -324,7 +380,29 @@ void launch_find_token_chunks(const CorpusDev &C, const uint64_t *begin, uint32_
 }
 
 void launch_count_sel(const uint32_t *sel, uint32_t nchunks, uint32_t *n_sel, hipStream_t stream) {
-	hipLaunchKernelGGL(count_sel_kernel, dim3(1), dim3(1024), 0, stream, sel, nchunks, n_sel);
+	hipLaunchKernelGGL(count_sel_kernel, dim3(1), dim3(1024), 0, stream, sel, (nchunks + 31) / 32, n_sel);
+}
+
+void launch_index_all(const TrieDev &T, const CorpusDev &C, const int32_t *slot_row, const uint64_t *begin,
+                      uint32_t nchunks, uint64_t chunk_bytes, uint32_t rows, uint32_t *index, uint32_t *row_chunks,
+                      hipStream_t stream) {
+	if (nchunks == 0 || rows == 0) return;
+	const uint32_t wpr = (nchunks + 31) / 32;
+	if (C.total) {
+		const uint32_t blocks = (uint32_t)std::min<uint64_t>((C.total + 255) / 256, 1u << 20);
+		hipLaunchKernelGGL(index_all_kernel, dim3(blocks), dim3(256), 0, stream, T, C, slot_row, begin, nchunks, chunk_bytes,
+		                   wpr, index);
+	}
+	hipLaunchKernelGGL(index_row_counts_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, index, rows, wpr, row_chunks);
+}
+
+void launch_or_rows(const uint32_t *index, const uint32_t *rows, uint32_t n, uint32_t nchunks, uint32_t *sel,
+                    hipStream_t stream) {
+	RowList L;
+	L.n = n < 8 ? n : 8;
+	for (uint32_t k = 0; k < L.n; k++) L.row[k] = rows[k];
+	const uint32_t wpr = (nchunks + 31) / 32;
+	hipLaunchKernelGGL(or_rows_kernel, dim3((wpr + 255) / 256), dim3(256), 0, stream, index, L, wpr, sel);
 }
 
 void launch_finalize(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, hipStream_t stream) {

@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 		if (lane == 0) j = atomicAdd(&Qd.cursor[kQueueHeadWord + queue * kQueueHeadStride], 1u);
 		j = __builtin_amdgcn_readfirstlane(j) * kWorkQueues + queue;
 		if (j >= S.nchunks) break;
-		if (chunk_sel && chunk_sel[j] == 0) continue; // incremental re-score: only the selected chunks
+		if (chunk_sel && !((chunk_sel[j >> 5] >> (j & 31)) & 1u)) continue; // incremental re-score: only the selected chunks
 		const uint64_t begin = S.begin[j];
 		const uint64_t end = S.begin[j + 1];
 		uint64_t di = chunk_first_doc[j]; // index of the first document offset >= begin

@@ -92,7 +92,12 @@ struct tokscore_ctx {
 	uint32_t nchunks = 0;
 	uint32_t unsynced = 0; // chunks whose entry is speculated (not at a guaranteed token start)
 	bool uniform_chunks = false; // boundaries at multiples of chunk_bytes, each moved forward by < chunk_bytes
-	uint32_t *d_sel = nullptr;   // [nchunks] chunk selection of an incremental re-score, + 1 word: their number
+	uint32_t *d_sel = nullptr;   // chunk bitmap of an incremental re-score, + 1 word: the number of bits set
+	// occurrence index (one bit per string and chunk), built by the first incremental re-score of a plan
+	uint32_t *d_index = nullptr;
+	int index_state = 0; // 0 not tried, 1 built, -1 not available (too large / allocation failed)
+	std::vector<int32_t> tok_row;        // token -> index row
+	std::vector<uint32_t> row_chunks;    // row -> number of chunks the string occurs in
 	void *d_stream = nullptr;
 	uint32_t stream_cap_batches = 0;
 	uint32_t *d_fill = nullptr;
@@ -147,6 +152,9 @@ void free_plan(tokscore_ctx *c) {
 	c->d_fill = nullptr;
 	if (c->d_sel) (void)hipFree(c->d_sel);
 	c->d_sel = nullptr;
+	if (c->d_index) (void)hipFree(c->d_index);
+	c->d_index = nullptr;
+	c->index_state = 0;
 	if (c->d_slab) (void)hipFree(c->d_slab);
 	c->d_chunk_begin = nullptr;
 	c->d_chunk_state = nullptr;
@@ -313,7 +321,7 @@ int ensure_plan(tokscore_ctx *c) {
 		HIP_TRY(c, hipMemcpy(c->d_chunk_first_doc, first.data(), first.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, kCursorWords * sizeof(uint32_t)));
-	HIP_TRY(c, hipMalloc((void **)&c->d_sel, ((size_t)c->nchunks + 1) * sizeof(uint32_t)));
+	HIP_TRY(c, hipMalloc((void **)&c->d_sel, ((size_t)(c->nchunks + 31) / 32 + 1) * sizeof(uint32_t)));
 	if (c->scan_path == 1) {
 		// Token stream: one entry per emitted token plus the repair rounds' +/- entries, in
 		// log blocks that are partly empty.  3 entries per corpus byte is far above anything
@@ -397,6 +405,47 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	HIP_TRY(c, hipGetLastError());
 	c->timing_pending = true;
 	return TOKSCORE_OK;
+}
+
+// Occurrence index for incremental re-scores (kernels_generic.hip: index_all_kernel).  Skipped
+// when it would take more than TOKSCORE_INDEX_MB (default 2048) of HBM; the re-score then
+// searches the corpus for each toggled string instead.
+void build_index(tokscore_ctx *c) {
+	c->index_state = -1;
+	std::vector<int32_t> slot_row;
+	const uint32_t rows = c->trie.StringRows(c->packed.slots.size(), &slot_row, &c->tok_row);
+	const uint32_t wpr = (c->nchunks + 31) / 32;
+	const uint64_t bytes = (uint64_t)rows * wpr * sizeof(uint32_t);
+	if (rows == 0 || bytes > env_u64("TOKSCORE_INDEX_MB", 2048) * (1ull << 20)) return;
+	int32_t *d_slot_row = nullptr;
+	uint32_t *d_counts = nullptr;
+	bool ok = hipMalloc((void **)&c->d_index, bytes) == hipSuccess &&
+	          hipMalloc((void **)&d_slot_row, slot_row.size() * sizeof(int32_t)) == hipSuccess &&
+	          hipMalloc((void **)&d_counts, rows * sizeof(uint32_t)) == hipSuccess;
+	if (ok) {
+		c->row_chunks.assign(rows, 0);
+		TrieDev T = trie_dev(c);
+		CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+		ok = hipMemsetAsync(c->d_index, 0, bytes, c->stream) == hipSuccess &&
+		     hipMemcpyAsync(d_slot_row, slot_row.data(), slot_row.size() * sizeof(int32_t), hipMemcpyHostToDevice,
+		                    c->stream) == hipSuccess;
+		if (ok) {
+			launch_index_all(T, C, d_slot_row, c->d_chunk_begin, c->nchunks, c->chunk_bytes, rows, c->d_index, d_counts,
+			                 c->stream);
+			ok = hipMemcpyAsync(c->row_chunks.data(), d_counts, rows * sizeof(uint32_t), hipMemcpyDeviceToHost,
+			                    c->stream) == hipSuccess &&
+			     hipStreamSynchronize(c->stream) == hipSuccess;
+		}
+	}
+	if (d_slot_row) (void)hipFree(d_slot_row);
+	if (d_counts) (void)hipFree(d_counts);
+	if (ok) {
+		c->index_state = 1;
+	} else {
+		(void)hipGetLastError();
+		if (c->d_index) (void)hipFree(c->d_index);
+		c->d_index = nullptr;
+	}
 }
 
 int check_overflow(tokscore_ctx *c) {
@@ -680,22 +729,44 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		c->ev = c->ring[c->calls % tokscore_ctx::kRing];
 		c->calls++;
 		HIP_TRY(c, hipEventRecord(c->ev[0], s));
-		HIP_TRY(c, hipMemsetAsync(c->d_sel, 0, ((size_t)c->nchunks + 1) * sizeof(uint32_t), s));
-		for (size_t k = 0; k < c->pending.size(); k++) {
-			const uint64_t tok = c->pending[k].first;
-			bool seen = false;
-			for (size_t m = 0; m < k; m++) seen = seen || c->pending[m].first == tok;
-			const uint64_t len = c->h_vocab_off[tok + 1] - c->h_vocab_off[tok];
-			if (seen || len == 0) continue;
-			launch_find_token_chunks(C, c->d_chunk_begin, c->nchunks, c->chunk_bytes, c->d_vocab_bytes + c->h_vocab_off[tok],
-			                         (uint32_t)len, c->d_sel, s);
-		}
-		launch_count_sel(c->d_sel, c->nchunks, c->d_sel + c->nchunks, s);
-		HIP_TRY(c, hipMemcpyAsync(&nsel, c->d_sel + c->nchunks, sizeof nsel, hipMemcpyDeviceToHost, s));
-		HIP_TRY(c, hipStreamSynchronize(s));
-		if (nsel > c->nchunks / 3) {
-			c->calls--; // this call's event set goes to the full evaluation
-			return tokscore_score(c, counts, total_tokens, total_bytes);
+		if (c->index_state == 0) build_index(c);
+		const uint32_t limit = c->nchunks / 12; // beyond this a full evaluation is as fast
+		if (c->index_state == 1) {
+			// the index knows the chunks (and how many) without a search or a host sync
+			uint32_t rows[8], nrows = 0;
+			for (size_t k = 0; k < c->pending.size(); k++) {
+				const int32_t r = c->tok_row[c->pending[k].first];
+				bool seen = r < 0;
+				for (uint32_t m = 0; m < nrows; m++) seen = seen || rows[m] == (uint32_t)r;
+				if (!seen) {
+					rows[nrows++] = (uint32_t)r;
+					nsel += c->row_chunks[r]; // an upper bound when rows overlap
+				}
+			}
+			if (nsel > limit) {
+				c->calls--; // this call's event set goes to the full evaluation
+				return tokscore_score(c, counts, total_tokens, total_bytes);
+			}
+			if (nsel) launch_or_rows(c->d_index, rows, nrows, c->nchunks, c->d_sel, s);
+		} else {
+			HIP_TRY(c, hipMemsetAsync(c->d_sel, 0, ((size_t)(c->nchunks + 31) / 32 + 1) * sizeof(uint32_t), s));
+			for (size_t k = 0; k < c->pending.size(); k++) {
+				const uint64_t tok = c->pending[k].first;
+				bool seen = false;
+				for (size_t m = 0; m < k; m++) seen = seen || c->pending[m].first == tok;
+				const uint64_t len = c->h_vocab_off[tok + 1] - c->h_vocab_off[tok];
+				if (seen || len == 0) continue;
+				launch_find_token_chunks(C, c->d_chunk_begin, c->nchunks, c->chunk_bytes,
+				                         c->d_vocab_bytes + c->h_vocab_off[tok], (uint32_t)len, c->d_sel, s);
+			}
+			uint32_t *d_n = c->d_sel + (c->nchunks + 31) / 32;
+			launch_count_sel(c->d_sel, c->nchunks, d_n, s);
+			HIP_TRY(c, hipMemcpyAsync(&nsel, d_n, sizeof nsel, hipMemcpyDeviceToHost, s));
+			HIP_TRY(c, hipStreamSynchronize(s));
+			if (nsel > limit) {
+				c->calls--;
+				return tokscore_score(c, counts, total_tokens, total_bytes);
+			}
 		}
 		HIP_TRY(c, hipEventRecord(c->ev[1], s));
 		if (nsel) {

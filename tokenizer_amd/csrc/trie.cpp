@@ -223,6 +223,21 @@ bool VocabTrie::Pack(PackedTrie *out, std::string *err) {
 	return true;
 }
 
+uint32_t VocabTrie::StringRows(uint64_t nslots, std::vector<int32_t> *slot_row, std::vector<int32_t> *tok_row) const {
+	slot_row->assign(nslots, -1);
+	tok_row->assign(V_, -1);
+	uint32_t rows = 0;
+	if (node_slot_.empty()) return 0;
+	for (uint64_t i = 0; i < V_; i++) {
+		const uint32_t node = tok_node_[i];
+		if (node == 0) continue; // empty string
+		int32_t &r = (*slot_row)[node_slot_[node]];
+		if (r < 0) r = (int32_t)rows++;
+		(*tok_row)[i] = r;
+	}
+	return rows;
+}
+
 int64_t VocabTrie::Toggle(uint64_t token, bool enable, PackedTrie *packed, uint64_t *new_entry) {
 	if (token >= V_) return -1;
 	enabled_[token] = enable ? 1 : 0;

@@ -58,6 +58,10 @@ public:
 	// new packed value for it so the caller can patch the device copy.
 	int64_t Toggle(uint64_t token, bool enable, PackedTrie *packed, uint64_t *new_entry);
 
+	// Rows of a per-string table (one row per distinct non-empty token string): slot_row[t] = row
+	// of the node at slot t or -1, tok_row[i] = row of token i's string or -1.  After Pack.
+	uint32_t StringRows(uint64_t nslots, std::vector<int32_t> *slot_row, std::vector<int32_t> *tok_row) const;
+
 	uint64_t vocab_size() const { return V_; }
 	uint64_t max_len() const { return max_len_; }
 	uint64_t node_count() const { return (uint64_t)first_child_.size(); }
