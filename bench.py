@@ -179,6 +179,10 @@ def main():
         scan_avg_ms = float(np.mean(scan_ms))
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(int(info.corpus_bytes))
+        # what a kernel that only reads gets out of this box: over 4 GiB (HBM)
+        # and over a buffer of the shard's size (which the 256 MB last-level cache holds)
+        stream_hbm = scorer.probe_read_bandwidth(4 << 30, 5)
+        stream_shard = scorer.probe_read_bandwidth(max(1 << 20, int(info.corpus_bytes)), 20)
         rec = {
             "metric": "corpus GB/s scored per full-vocab eval",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -194,7 +198,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "scan_tile_kernel" if info.scan_path == 1 else "scan_generic_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": scan_avg_ms,
-                         "eval_kernels_ms": float(np.mean(eval_ms))},
+                         "eval_kernels_ms": float(np.mean(eval_ms)),
+                         "measured_stream_read_GBps": {"hbm_4GiB": stream_hbm, "shard_sized_buffer": stream_shard},
+                         "frac_of_measured_hbm_stream": achieved / stream_hbm if stream_hbm else None},
             "total_tokens": int(host[V + 3]), "h2d_inclusive_GBps": info.corpus_bytes / (h2d_s + elapsed / args.steps) / 1e9,
         }
         if world == 1 and not args.no_cpu:

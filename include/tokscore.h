@@ -157,6 +157,13 @@ int tokscore_last_timing(tokscore_ctx *ctx, float ms[4]);
  * floats; *n receives the number of calls reported. */
 int tokscore_drain_timings(tokscore_ctx *ctx, float *ms, uint32_t cap, uint32_t *n);
 
+/* Measurement aid ("report against a measured read-only streaming kernel
+ * on the same box"); no counterpart in the reference.  Reads a zeroed scratch buffer of `bytes`
+ * (>= 1 MiB; allocated and freed inside) `reps` times with a kernel that only loads, and
+ * reports the rate in 10^9 bytes per second.  Buffers below the 256 MB last-level cache
+ * measure that cache, larger ones HBM. */
+int tokscore_probe_read_bandwidth(tokscore_ctx *ctx, uint64_t bytes, uint32_t reps, double *gb_per_s);
+
 /* Host-side self-check of the packed double-array trie (no GPU involved, used by the
  * CPU test-suite to validate the builder): longest enabled vocabulary entry that is a
  * prefix of text[0..n).  *len = 0 when none.  Never used by any scoring entry point. */

@@ -54,6 +54,7 @@ _SIGNATURES = [
     ("tokscore_last_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("tokscore_drain_timings", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     ("tokscore_hosttrie_longest", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u64p]),
+    ("tokscore_probe_read_bandwidth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
 
@@ -200,6 +201,12 @@ class Scorer:
         n = C.c_uint32()
         self._check(self._lib.tokscore_drain_timings(self._h, ms, cap, C.byref(n)))
         return [[float(ms[4 * i + k]) for k in range(4)] for i in range(int(n.value))]
+
+    def probe_read_bandwidth(self, nbytes: int, reps: int = 10) -> float:
+        """GB/s a read-only streaming kernel reaches on this GPU over a buffer of nbytes."""
+        v = C.c_double()
+        self._check(self._lib.tokscore_probe_read_bandwidth(self._h, nbytes, reps, C.byref(v)))
+        return float(v.value)
 
     def hosttrie_longest(self, text: bytes):
         a = np.frombuffer(text, dtype=np.uint8) if text else np.zeros(1, dtype=np.uint8)

@@ -28,6 +28,7 @@ void launch_index_all(const TrieDev &T, const CorpusDev &C, const int32_t *slot_
                       hipStream_t stream);
 void launch_or_rows(const uint32_t *index, const uint32_t *rows, uint32_t n, uint32_t nchunks, uint32_t *sel,
                     hipStream_t stream);
+void launch_read_probe(const void *buf, uint64_t bytes, uint32_t blocks, uint32_t *sink, hipStream_t stream);
 void launch_finalize(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, hipStream_t stream);
 void launch_tokenize_one(const TrieDev &T, const uint8_t *text, uint64_t n, unsigned long long *ids, uint64_t cap,
                          unsigned long long *n_ids, hipStream_t stream);

@@ -414,4 +414,30 @@ void launch_tokenize_one(const TrieDev &T, const uint8_t *text, uint64_t n, unsi
 	hipLaunchKernelGGL(tokenize_one_kernel, dim3(1), dim3(64), 0, stream, T, text, n, ids, cap, n_ids);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Read-only streaming probe ("report against a measured read-only streaming
+// kernel on the same box"): what this GPU's memory system delivers to a kernel that does nothing
+// but read.  16 bytes per lane and load, four loads in flight per lane, grid-stride.
+typedef uint32_t probe_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void read_probe_kernel(const probe_v4 *__restrict__ p, uint64_t n16, uint32_t *sink) {
+	const uint64_t stride = (uint64_t)gridDim.x * 256;
+	uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+	probe_v4 a = 0, b = 0, c = 0, d = 0;
+	for (; i + 3 * stride < n16; i += 4 * stride) {
+		const probe_v4 v0 = __builtin_nontemporal_load(p + i);
+		const probe_v4 v1 = __builtin_nontemporal_load(p + i + stride);
+		const probe_v4 v2 = __builtin_nontemporal_load(p + i + 2 * stride);
+		const probe_v4 v3 = __builtin_nontemporal_load(p + i + 3 * stride);
+		a ^= v0, b ^= v1, c ^= v2, d ^= v3;
+	}
+	for (; i < n16; i += stride) a ^= __builtin_nontemporal_load(p + i);
+	a ^= b ^ c ^ d;
+	const uint32_t x = a.x + a.y + a.z + a.w;
+	if (x == 0x9E3779B9u) sink[0] = x; // keeps the loads alive; the buffer is all zero
+}
+
+void launch_read_probe(const void *buf, uint64_t bytes, uint32_t blocks, uint32_t *sink, hipStream_t stream) {
+	hipLaunchKernelGGL(read_probe_kernel, dim3(blocks), dim3(256), 0, stream, (const probe_v4 *)buf, bytes / 16, sink);
+}
+
 } // namespace tokscore

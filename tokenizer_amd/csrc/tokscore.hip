@@ -22,6 +22,7 @@ namespace {
 constexpr uint64_t kCorpusPad = 4096;         // readable zero bytes past the corpus end (tile halo)
 constexpr uint64_t kSampleBytes = 2u << 20;   // host sample for the hot-first trie layout
 constexpr uint64_t kSamplePieces = 16;
+constexpr size_t kMaxPatch = 8;               // toggles an incremental re-score takes in one go
 
 uint64_t env_u64(const char *name, uint64_t dflt) {
 	const char *s = getenv(name);
@@ -108,6 +109,11 @@ struct tokscore_ctx {
 	// outputs
 	unsigned long long *d_out = nullptr;
 	uint64_t d_out_cap = 0;
+	// pinned: the result as it comes back (V+5 words + the stream cursor pair) and the slot
+	// values of the pending toggles, so that neither copy stalls the host
+	uint64_t *h_out = nullptr;
+	uint64_t *h_patch = nullptr;
+	bool patch_in_flight = false; // h_patch may still be read by a copy nobody waited for
 	float last_ms[4] = {0, 0, 0, 0};
 	bool timing_pending = false;
 };
@@ -244,9 +250,18 @@ int ensure_trie(tokscore_ctx *c) {
 int apply_pending(tokscore_ctx *c, hipStream_t s) {
 	if (c->pending.empty()) return TOKSCORE_OK;
 	if (c->device_trie_valid) {
-		for (const auto &pd : c->pending)
-			HIP_TRY(c, hipMemcpyAsync(c->d_slots + pd.second, &c->packed.slots[pd.second], sizeof(uint64_t),
-			                          hipMemcpyHostToDevice, s));
+		const bool staged = c->h_patch && s == c->stream && !c->patch_in_flight && c->pending.size() <= kMaxPatch;
+		size_t k = 0;
+		for (const auto &pd : c->pending) {
+			const uint64_t *src = &c->packed.slots[pd.second];
+			if (staged) {
+				// (the previous batch was consumed: every caller waits for its stream before it returns)
+				c->h_patch[k] = *src;
+				src = &c->h_patch[k++];
+			}
+			HIP_TRY(c, hipMemcpyAsync(c->d_slots + pd.second, src, sizeof(uint64_t), hipMemcpyHostToDevice, s));
+		}
+		if (staged) c->patch_in_flight = true; // until the next wait on c->stream (fetch_out)
 	}
 	c->pending.clear();
 	return TOKSCORE_OK;
@@ -348,8 +363,24 @@ int ensure_out(tokscore_ctx *c) {
 		if (c->d_out) (void)hipFree(c->d_out);
 		c->d_out = nullptr;
 		HIP_TRY(c, hipMalloc((void **)&c->d_out, n * sizeof(unsigned long long)));
+		if (c->h_out) (void)hipHostFree(c->h_out);
+		c->h_out = nullptr;
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_out, (n + 1) * sizeof(uint64_t), hipHostMallocDefault));
 		c->d_out_cap = n;
 	}
+	if (!c->h_patch) HIP_TRY(c, hipHostMalloc((void **)&c->h_patch, kMaxPatch * sizeof(uint64_t), hipHostMallocDefault));
+	return TOKSCORE_OK;
+}
+
+// d_out and the scan's overflow flag into h_out, one wait.
+int fetch_out(tokscore_ctx *c, hipStream_t s) {
+	const uint64_t n = c->V + 5;
+	c->h_out[n] = 0;
+	HIP_TRY(c, hipMemcpyAsync(c->h_out, c->d_out, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+	if (c->scan_path == 1 && c->d_cursor)
+		HIP_TRY(c, hipMemcpyAsync(c->h_out + n, c->d_cursor, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	HIP_TRY(c, hipStreamSynchronize(s));
+	c->patch_in_flight = false;
 	return TOKSCORE_OK;
 }
 
@@ -448,11 +479,9 @@ void build_index(tokscore_ctx *c) {
 	}
 }
 
-int check_overflow(tokscore_ctx *c) {
+int check_overflow(tokscore_ctx *c) { // after fetch_out
 	if (c->scan_path != 1) return TOKSCORE_OK;
-	uint32_t cur[2] = {0, 0};
-	HIP_TRY(c, hipMemcpy(cur, c->d_cursor, sizeof cur, hipMemcpyDeviceToHost));
-	if (cur[1]) return fail(c, TOKSCORE_E_CAPACITY, "token stream overflow (internal capacity bound violated)");
+	if (c->h_out[c->V + 5] >> 32) return fail(c, TOKSCORE_E_CAPACITY, "token stream overflow (internal capacity bound violated)");
 	return TOKSCORE_OK;
 }
 
@@ -535,6 +564,8 @@ void tokscore_destroy(tokscore_ctx *c) {
 		if (c->d_slots) (void)hipFree(c->d_slots);
 		if (c->d_vocab_bytes) (void)hipFree(c->d_vocab_bytes);
 		if (c->d_out) (void)hipFree(c->d_out);
+		if (c->h_out) (void)hipHostFree(c->h_out);
+		if (c->h_patch) (void)hipHostFree(c->h_patch);
 		for (auto &set : c->ring)
 			for (auto &e : set)
 				if (e) (void)hipEventDestroy(e);
@@ -683,9 +714,9 @@ int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, ui
 	if (st) return st;
 	st = enqueue_score(c, c->d_out, c->stream);
 	if (st) return st;
-	std::vector<uint64_t> host(c->V + 5);
-	HIP_TRY(c, hipMemcpyAsync(host.data(), c->d_out, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
-	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	st = fetch_out(c, c->stream);
+	if (st) return st;
+	const uint64_t *host = c->h_out;
 	st = check_overflow(c);
 	if (st == TOKSCORE_E_CAPACITY && !c->force_generic) {
 		// adversarial input blew the stream bound: redo this evaluation on the generic path
@@ -696,7 +727,7 @@ int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, ui
 	if (st) return st;
 	c->state_valid = true; // d_out = this evaluation, the device trie = the vocabulary it used
 	c->rescored_chunks = 0xFFFFFFFFu;
-	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
+	memcpy(counts, host, (c->V + 3) * sizeof(uint64_t));
 	if (total_tokens) *total_tokens = host[c->V + 3];
 	if (total_bytes) *total_bytes = host[c->V + 4];
 	return TOKSCORE_OK;
@@ -714,11 +745,10 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
 	(void)hipSetDevice(c->device);
 	const bool eligible = c->state_valid && c->plan_valid && c->packed_valid && c->device_trie_valid && c->d_vocab_valid &&
-	                      c->scan_path == 1 && c->unsynced == 0 && c->uniform_chunks && c->pending.size() <= 8 &&
+	                      c->scan_path == 1 && c->unsynced == 0 && c->uniform_chunks && c->pending.size() <= kMaxPatch &&
 	                      !env_u64("TOKSCORE_NOINCR", 0);
 	if (!eligible) return tokscore_score(c, counts, total_tokens, total_bytes);
 	hipStream_t s = c->stream;
-	std::vector<uint64_t> host(c->V + 5);
 	uint32_t nsel = 0;
 	if (!c->pending.empty()) {
 		TrieDev T = trie_dev(c);
@@ -788,12 +818,13 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		HIP_TRY(c, hipGetLastError());
 		c->timing_pending = true;
 	}
-	HIP_TRY(c, hipMemcpyAsync(host.data(), c->d_out, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-	HIP_TRY(c, hipStreamSynchronize(s));
+	int st = fetch_out(c, s);
+	if (st) return st;
+	const uint64_t *host = c->h_out;
 	if (nsel) {
 		// (two passes share the overflow flag: prepare clears it, so this sees the second one;
 		// a partial scan holds at most a third of what a full one is sized for)
-		int st = check_overflow(c);
+		st = check_overflow(c);
 		if (st) {
 			c->force_generic = true;
 			c->plan_valid = false;
@@ -802,7 +833,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 	}
 	c->state_valid = true;
 	c->rescored_chunks = nsel;
-	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
+	memcpy(counts, host, (c->V + 3) * sizeof(uint64_t));
 	if (total_tokens) *total_tokens = host[c->V + 3];
 	if (total_bytes) *total_bytes = host[c->V + 4];
 	return TOKSCORE_OK;
@@ -850,6 +881,38 @@ int tokscore_count_occurrences(tokscore_ctx *c, uint32_t max_cp, uint64_t *count
 	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("count_occurrences: ") + hipGetErrorString(e));
 	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
 	if (positions) *positions = host[c->V + 3];
+	return TOKSCORE_OK;
+}
+
+int tokscore_probe_read_bandwidth(tokscore_ctx *c, uint64_t bytes, uint32_t reps, double *gb_per_s) {
+	if (!c || !gb_per_s || reps == 0) return fail(c, TOKSCORE_E_ARG, "null output or zero repetitions");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	bytes &= ~(uint64_t)4095;
+	if (bytes < (1u << 20)) return fail(c, TOKSCORE_E_ARG, "probe buffer below 1 MiB");
+	(void)hipSetDevice(c->device);
+	uint8_t *buf = nullptr;
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	float ms = 0.f;
+	hipError_t e = hipMalloc((void **)&buf, bytes + 256);
+	do {
+		if (e != hipSuccess) break;
+		if ((e = hipEventCreate(&e0)) != hipSuccess || (e = hipEventCreate(&e1)) != hipSuccess) break;
+		if ((e = hipMemsetAsync(buf, 0, bytes + 256, c->stream)) != hipSuccess) break;
+		uint32_t *sink = (uint32_t *)(buf + bytes);
+		const uint32_t blocks = (uint32_t)std::min<uint64_t>((uint64_t)c->num_cus * 16, (bytes / 16 + 255) / 256);
+		launch_read_probe(buf, bytes, blocks, sink, c->stream); // warm-up (page tables, clocks)
+		if ((e = hipEventRecord(e0, c->stream)) != hipSuccess) break;
+		for (uint32_t r = 0; r < reps; r++) launch_read_probe(buf, bytes, blocks, sink, c->stream);
+		if ((e = hipEventRecord(e1, c->stream)) != hipSuccess) break;
+		if ((e = hipEventSynchronize(e1)) != hipSuccess) break;
+		if ((e = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) break;
+		e = hipGetLastError();
+	} while (0);
+	if (e0) (void)hipEventDestroy(e0);
+	if (e1) (void)hipEventDestroy(e1);
+	if (buf) (void)hipFree(buf);
+	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("probe_read_bandwidth: ") + hipGetErrorString(e));
+	*gb_per_s = ms > 0.f ? (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
 	return TOKSCORE_OK;
 }
 
