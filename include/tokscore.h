@@ -72,9 +72,11 @@ int tokscore_vocab_max_len(const tokscore_ctx *ctx, uint64_t *max_len);
 
 /* Annealing move on the scored vocabulary: disable / re-enable entry `token_index`
  * without rebuilding the trie.  A disabled entry can never be emitted; if a later entry
- * holds the same string it takes over, exactly as in the vocabulary without the entry.  There is no reference counterpart on the corpus
- * path: the reference judges moves on the candidate DAG (src/tokenizer/Token.cpp:83-105);
- * parity is defined as "equal to a full score with the toggled vocabulary". */
+ * holds the same string it takes over, exactly as in the vocabulary without the entry.
+ * The call only queues the change (one 8-byte trie slot); the next evaluation applies it.
+ * There is no reference counterpart on the corpus path: the reference judges moves on the
+ * candidate DAG (src/tokenizer/Token.cpp:83-105); parity is defined as "equal to a full
+ * score with the toggled vocabulary". */
 int tokscore_toggle(tokscore_ctx *ctx, uint64_t token_index, int enable);
 
 /* Corpus in --------------------------------------------------------------------
@@ -104,7 +106,12 @@ int tokscore_score(tokscore_ctx *ctx, uint64_t *counts, uint64_t *total_tokens, 
  * enqueued on `stream` (a hipStream_t, or NULL for the context's own stream). */
 int tokscore_score_async(tokscore_ctx *ctx, void *d_out, void *stream);
 
-/* Re-score after tokscore_toggle calls: identical results to tokscore_score. */
+/* Re-score after tokscore_toggle calls: identical results to tokscore_score, bit for bit.
+ * Only the work chunks that contain a toggled entry's string are scanned again (with the
+ * trie as it was: subtracted; as it is: added) on top of the previous evaluation's counts,
+ * which stay in device memory.  Falls back to a full evaluation by itself when there is no
+ * previous evaluation, more than 8 toggles are pending, or the strings occur in more than
+ * 1/12 of the chunks; tokscore_info.rescored_chunks reports what the call did. */
 int tokscore_score_incremental(tokscore_ctx *ctx, uint64_t *counts, uint64_t *total_tokens,
                                uint64_t *total_bytes);
 
@@ -120,6 +127,23 @@ int tokscore_score_incremental(tokscore_ctx *ctx, uint64_t *counts, uint64_t *to
  *                 string counts on its first id); counts[0], counts[1], counts[V+2] are 0
  *   positions     number of code-point positions (the trie root's freq, Trie.cpp:117) */
 int tokscore_count_occurrences(tokscore_ctx *ctx, uint32_t max_cp, uint64_t *counts, uint64_t *positions);
+
+/* Open-vocabulary candidate extraction: the candidate set
+ * annealing::GetTokens builds from the corpus -- FileCandidates + Trie::BuildTokens
+ * (src/tokenizer/GetTokens.cpp:21-90, src/tokenizer/Trie.cpp:81-152) -- for the resident
+ * corpus, computed on the GPU by sorting all windows of 1 .. max_cp code points (no trie is
+ * built).  Token t of the result is the t-th node of the reference's trie in pre-order
+ * (children by code point): chr[t] = FIRST code point of its string (Trie.cpp:81-89),
+ * uses[t] = its occurrence count (Trie.cpp:82), lpar[t] / rpar[t] = index of the string minus
+ * its first / last code point, 0xFFFFFFFF for single code points (Trie.cpp:92-103) -- the
+ * arrays tokanneal_cands_from_arrays (include/tokanneal.h) takes, and what WriteTokens stores.
+ * The corpus must be valid UTF-8 without NUL bytes, below 4 GiB; max_cp <= 32.
+ *   tokscore_extract_candidates  runs the extraction; *n_tokens = number of tokens,
+ *                                *positions = code points in the corpus (may be NULL)
+ *   tokscore_candidates_copy     copies the arrays (n_tokens entries each; any pointer may be
+ *                                NULL) to the host and releases the device copy */
+int tokscore_extract_candidates(tokscore_ctx *ctx, uint32_t max_cp, uint64_t *n_tokens, uint64_t *positions);
+int tokscore_candidates_copy(tokscore_ctx *ctx, uint32_t *chr, uint64_t *uses, uint32_t *lpar, uint32_t *rpar);
 
 /* Per-document id sequence, the exact return value of
  * SolutionFile::Tokenize(std::string) (src/files/SolutionFile.cpp:83-100) for one

@@ -18,6 +18,12 @@
 //       GetTokens on a tiny corpus, then a scripted single-threaded toggle
 //       sequence through Token::SimulateStep / Token::ApplyStep<bool>
 //       (Token.cpp:83-105), dumping the DAG and every return value.
+//   trace  <data_dir> <max_len> <pref> <batch> <seed> <ntasks> <out.json>
+//       GetTokens -> TokenGenerator, the calling thread's generator (the
+//       thread_local `gen` of TokenGenerator.cpp:52) seeded with <seed>, then
+//       <ntasks> TokenGenerator::WorkerTask calls on this thread, the state after
+//       each one, and GetSolution at the end.  GetTokens leaves its
+//       `.candidates-all-<max_len>.bin` (WriteTokens, Token.cpp:163-193) in <data_dir>.
 //
 // Only this file is ours; every symbol it calls is the reference's.
 #include <atomic>
@@ -177,7 +183,14 @@ static int cmd_anneal(int argc, char **argv) {
 		std::vector<annealing::Token> tokens =
 		    annealing::GetTokens(metadata, (uint8_t)max_len, -1, true); // main.cpp:20
 		annealing::TokenGenerator generator(std::move(tokens), pref, batch); // :21
+		auto t0 = std::chrono::steady_clock::now();
 		generator.Generate(passes);                                   // :22
+		const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		// moves = gen_cnt_ increments / wall time
+		std::cerr << "{\"generate_seconds\": " << secs << ", \"gen_cnt\": " << (size_t)generator.gen_cnt_
+		          << ", \"tot_cand\": " << generator.tot_cand_ << ", \"enabled_cnt\": " << (size_t)generator.enabled_cnt_
+		          << ", \"threads\": " << std::min((uint64_t)std::thread::hardware_concurrency(), generator.tot_cand_ / batch)
+		          << "}" << std::endl;
 		solution = generator.GetSolution();                           // :24
 	}
 	SolutionFile tkn(solution, argv[7]);                              // :26
@@ -257,9 +270,51 @@ static int cmd_cands(int argc, char **argv) {
 	return 0;
 }
 
+// TokenGenerator.cpp:51-53 defines these at namespace scope with external linkage
+extern thread_local std::mt19937 gen;
+
+static int cmd_trace(int argc, char **argv) {
+	if (argc < 9) return 2;
+	silence_stdin();
+	const std::string dir = argv[2];
+	const int max_len = atoi(argv[3]);
+	const size_t pref = strtoull(argv[4], nullptr, 10);
+	const size_t batch = strtoull(argv[5], nullptr, 10);
+	const uint32_t seed = (uint32_t)strtoull(argv[6], nullptr, 10);
+	const size_t ntasks = strtoull(argv[7], nullptr, 10);
+	MetadataFile metadata(dir + "/.metadata.json", true);
+	std::vector<annealing::Token> tokens = annealing::GetTokens(metadata, (uint8_t)max_len, -1, true);
+	annealing::TokenGenerator g(std::move(tokens), pref, batch);
+	gen.seed(seed);
+	std::ofstream out(argv[8]);
+	out.precision(17);
+	auto dump = [&](bool first) {
+		double beta, sigma;
+		g.score_dist_.GetParams(&beta, &sigma);
+		out << (first ? "\n  " : ",\n  ") << "{\"gen_cnt\": " << (size_t)g.gen_cnt_ << ", \"enabled_cnt\": " << (size_t)g.enabled_cnt_
+		    << ", \"raw_score\": " << (double)g.raw_score_ << ", \"temp\": " << (double)g.temp_
+		    << ", \"moment1\": " << g.score_dist_.moment1_ << ", \"moment2\": " << g.score_dist_.moment2_
+		    << ", \"beta\": " << beta << ", \"sigma\": " << sigma << "}";
+	};
+	out << "{\"max_len\": " << max_len << ", \"pref\": " << pref << ", \"batch\": " << batch << ", \"seed\": " << seed
+	    << ", \"tot_cand\": " << g.tot_cand_ << ", \"n_tokens\": " << g.tokens_.size() << ",\n \"states\": [";
+	for (size_t k = 0; k < ntasks; k++) {
+		g.WorkerTask();
+		dump(k == 0);
+	}
+	out << "],\n \"solution\": [";
+	const std::vector<std::string> sol = g.GetSolution();
+	for (size_t i = 0; i < sol.size(); i++) {
+		out << (i ? ", " : "");
+		json_escape(out, sol[i]);
+	}
+	out << "]}\n";
+	return 0;
+}
+
 int main(int argc, char **argv) {
 	if (argc < 2) {
-		std::cerr << "usage: ref_harness score|anneal|dag|cands ..." << std::endl;
+		std::cerr << "usage: ref_harness score|anneal|dag|cands|trace ..." << std::endl;
 		return 2;
 	}
 	const std::string cmd = argv[1];
@@ -267,6 +322,7 @@ int main(int argc, char **argv) {
 	if (cmd == "anneal") return cmd_anneal(argc, argv);
 	if (cmd == "dag") return cmd_dag(argc, argv);
 	if (cmd == "cands") return cmd_cands(argc, argv);
+	if (cmd == "trace") return cmd_trace(argc, argv);
 	std::cerr << "unknown command " << cmd << std::endl;
 	return 2;
 }

@@ -101,6 +101,34 @@ def gen_cands():
     print("cands_mixed candidates=%d docs=%d" % (len(j["tokens"]), len(texts)))
 
 
+def gen_anneal():
+    # (14) f2 / f4: GetTokens' own `.candidates-all-5.bin` (WriteTokens) for a small mixed shard, and
+    # a single-threaded, seeded run of TokenGenerator::WorkerTask on it: the state after every
+    # task and GetSolution at the end (ref_harness `trace`).
+    texts = docs_of(*synth.wiki_like(4_000, seed=21, n_words=200, median_doc=500))
+    texts += docs_of(*synth.cjk_heavy(1_500, seed=22, doc_lo=64, doc_hi=500))
+    texts += ["Ünïcödé 𝄞𝄞 clef 𝄞", "b", "abababababababab"]
+    pref, batch, seed, ntasks, max_len = 150, 16, 12345, 700, 5
+    with tempfile.TemporaryDirectory() as tmp:
+        data = os.path.join(tmp, "data")
+        os.makedirs(data)
+        write_shard(os.path.join(data, "a.json"), texts)
+        out = os.path.join(tmp, "trace.json")
+        subprocess.run([HARNESS, "trace", data, str(max_len), str(pref), str(batch), str(seed), str(ntasks), out],
+                       check=True, cwd=tmp, stdout=subprocess.DEVNULL)
+        j = json.load(open(out))
+        blob = open(os.path.join(data, ".candidates-all-%d.bin" % max_len), "rb").read()
+    d = os.path.join(HERE, "anneal_mixed")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    j["docs"] = texts
+    with gzip.GzipFile(os.path.join(d, "trace.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(j, separators=(",", ":"), ensure_ascii=False).encode("utf-8"))
+    with gzip.GzipFile(os.path.join(d, "candidates.bin.gz"), "wb", mtime=0) as f:
+        f.write(blob)
+    print("anneal_mixed tokens=%d tot_cand=%d tasks=%d solution=%d bin=%d bytes"
+          % (j["n_tokens"], j["tot_cand"], len(j["states"]), len(j["solution"]), len(blob)))
+
 
 def main():
     if not os.path.exists(HARNESS):
@@ -200,10 +228,13 @@ def main():
         print("dag_tiny tokens=%d steps=%d" % (len(j["tokens"]), len(j["steps"])))
 
     gen_cands()
+    gen_anneal()
 
 
 if __name__ == "__main__":
     if sys.argv[1:] == ["cands"]:  # only the f1 case (the annealed cases are not reproducible bit for bit)
         gen_cands()
+    elif sys.argv[1:] == ["anneal"]:
+        gen_anneal()
     else:
         main()

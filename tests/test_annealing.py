@@ -1,0 +1,249 @@
+"""Rows a5 / f2 / f4: libtokanneal.so -- candidate DAG, `.candidates-*.bin`,
+move primitives and the annealing loop -- against what the COMPILED REFERENCE produced:
+
+    tests/golden/anneal_mixed/candidates.bin.gz   GetTokens' own WriteTokens output (Token.cpp:163-193)
+    tests/golden/anneal_mixed/trace.json.gz       ref_harness `trace`: a seeded single-threaded run of
+                                                  TokenGenerator::WorkerTask, the state after every task,
+                                                  GetSolution at the end; plus the documents
+    tests/golden/dag_tiny.json                    ref_harness `dag`: scripted SimulateStep / ApplyStep
+
+All host code: these run without a GPU.  Doubles are compared for equality -- the library does the
+reference's operations in the reference's order with the same libstdc++ generator/distributions."""
+import ctypes as C
+import gzip
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+from tokenizer_amd import annealing as A
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASE = os.path.join(O.GOLDEN, "anneal_mixed")
+
+
+@pytest.fixture(scope="module")
+def trace():
+    return json.loads(gzip.open(os.path.join(CASE, "trace.json.gz")).read().decode("utf-8"))
+
+
+@pytest.fixture(scope="module")
+def golden_bin(tmp_path_factory):
+    p = tmp_path_factory.mktemp("cands") / "golden.bin"
+    p.write_bytes(gzip.open(os.path.join(CASE, "candidates.bin.gz")).read())
+    return str(p)
+
+
+def pack_docs(texts):
+    docs = [t.encode("utf-8") for t in texts]
+    off = np.zeros(len(docs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(d) for d in docs], dtype=np.uint64)
+    corpus = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    return corpus, off
+
+
+def test_library_exports_every_declared_symbol():
+    text = open(os.path.join(ROOT, "include", "tokanneal.h")).read()
+    declared = sorted(set(re.findall(r"\b(tokanneal_[a-z_]+)\s*\(", text)))
+    assert declared == sorted(A.EXPORTED_SYMBOLS)
+    lib = C.CDLL(A.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert A.load_library().tokanneal_abi_version() == 100
+
+
+def test_read_tokens_parses_the_reference_file(trace, golden_bin):
+    code, toks = A.ReadTokens(golden_bin)
+    assert code == A.READ_OK
+    assert len(toks) == trace["n_tokens"]
+    chr_, uses, lpar, rpar = toks.arrays()
+    roots = rpar == A.NONE
+    assert np.array_equal(roots, lpar == A.NONE)
+    assert int((~roots).sum()) == trace["tot_cand"]
+    names = toks.names()
+    # the DAG's shape (Trie.cpp:92-103): l = the string minus its first code point, r = minus its last
+    for i in range(0, len(toks), 7):
+        s = names[i].decode("utf-8")
+        assert toks.GetName(i) == names[i] and toks.size(i) == len(s)
+        assert chr(int(chr_[i])) == s[0]
+        if len(s) > 1:
+            assert names[lpar[i]].decode("utf-8") == s[1:] and names[rpar[i]].decode("utf-8") == s[:-1]
+    # pre-order of a trie whose children are sorted by code point = sorted by code point sequence
+    cps = [tuple(ord(c) for c in n.decode("utf-8")) for n in names]
+    assert cps == sorted(cps) and len(set(cps)) == len(cps)
+
+
+def test_get_tokens_builds_the_reference_candidates(trace, golden_bin, tmp_path):
+    # FileCandidates + BuildTokens restated (hash trie, children ordered afterwards) against the
+    # reference's pointer trie: same tokens, same order, same counts, same parents ...
+    built = A.GetTokens(*pack_docs(trace["docs"]), max_len=trace["max_len"])
+    _, ref = A.ReadTokens(golden_bin)
+    for a, b in zip(built.arrays(), ref.arrays()):
+        assert np.array_equal(a, b)
+    # ... and WriteTokens writes the very file the reference wrote
+    out = tmp_path / A.candidates_file_name(None, trace["max_len"])
+    assert out.name == ".candidates-all-5.bin"
+    A.WriteTokens(str(out), built)
+    assert out.read_bytes() == open(golden_bin, "rb").read()
+    # uses are occurrence counts: check a few against a plain count over the documents
+    names = built.names()
+    uses = built.arrays()[1]
+    for i in (0, 11, 500, 4000, len(names) - 1):
+        s = names[i].decode("utf-8")
+        want = sum(sum(1 for k in range(len(d) - len(s) + 1) if d[k:k + len(s)] == s) for d in trace["docs"])
+        assert int(uses[i]) == want, s
+
+
+def test_read_tokens_error_codes(golden_bin, tmp_path):
+    blob = open(golden_bin, "rb").read()
+
+    def code_of(data):
+        p = tmp_path / "x.bin"
+        p.write_bytes(data)
+        return A.ReadTokens(str(p))[0]
+
+    assert A.ReadTokens(str(tmp_path / "missing.bin"))[0] == A.BAD_STREAM      # Token.cpp:110
+    assert code_of(b"0.3.9\x00" + blob[6:]) == A.INVALID_VERSION               # :115-116
+    assert code_of(b"0.4.0") == A.INVALID_VERSION
+    assert code_of(blob[:len(blob) // 2]) == A.BAD_FILE                        # :146
+    assert code_of(blob[:-3]) == A.BAD_FILE
+    assert code_of(blob + b"\x00") == A.NOT_DONE                               # :159
+    code, toks = A.ReadTokens(golden_bin)
+    assert code == A.READ_OK and len(toks) > 0
+    p = tmp_path / "empty.bin"
+    p.write_bytes(b"0.4.0\x00" + (0).to_bytes(8, "little"))                    # :121
+    code, toks = A.ReadTokens(str(p))
+    assert code == A.READ_OK and len(toks) == 0
+    # a parent index past the end is a corrupt file, not a crash
+    bad = bytearray(blob)
+    bad[-4:] = (0x7FFFFFFF).to_bytes(4, "little")
+    assert code_of(bytes(bad)) == A.BAD_FILE
+
+
+def test_varint_is_read_at_64_bits(tmp_path):
+    # the reference's reader shifts an int (Token.cpp:136) and breaks above 2^31 uses; the writer is fine
+    big = (1 << 40) + 12345
+    t = A.Tokens.from_arrays([ord("a"), ord("a")], [big, big - 7], [A.NONE, 0], [A.NONE, 0])
+    p = tmp_path / "big.bin"
+    A.WriteTokens(str(p), t)
+    code, back = A.ReadTokens(str(p))
+    assert code == A.READ_OK
+    assert [int(x) for x in back.arrays()[1]] == [big, big - 7]
+    assert back.GetName(1) == b"aa" and back.size(1) == 2
+
+
+def test_from_arrays_rejects_what_is_not_a_dag():
+    with pytest.raises(A.TokannealError):
+        A.Tokens.from_arrays([97, 97], [1, 1], [1, 0], [1, 0])              # a cycle
+    with pytest.raises(A.TokannealError):
+        A.Tokens.from_arrays([97, 97], [1, 1], [A.NONE, 5], [A.NONE, 0])    # out of range
+    with pytest.raises(A.TokannealError):
+        A.Tokens.from_arrays([97, 97], [1, 1], [A.NONE, A.NONE], [A.NONE, 0])  # a root on one side only
+
+
+def test_move_primitives_match_the_reference_dump():
+    g = json.load(open(os.path.join(O.GOLDEN, "dag_tiny.json"), encoding="utf-8"))
+    toks = g["tokens"]
+    none = lambda v: A.NONE if v < 0 else v  # noqa: E731
+    t = A.Tokens.from_arrays([x["chr"] for x in toks], [x["uses"] for x in toks], [none(x["l"]) for x in toks],
+                             [none(x["r"]) for x in toks])
+    assert [n.decode("utf-8") for n in t.names()] == [x["name"] for x in toks]
+    gen = A.TokenGenerator(t, 30000, 30)
+    assert len(t) == 0  # moved from
+    assert gen.state().tot_cand == g["tot_cand"]
+    for i, x in enumerate(toks):
+        assert gen.token_state(i) == (x["uses"], x["uses"], bool(x["enabled"]))
+    for s in g["steps"]:
+        assert gen.SimulateStep(s["i"]) == s["sim"], s
+        assert gen.ApplyStep(s["i"], bool(s["enable"])) == s["apply"], s
+    for i, (lu, ru, en) in enumerate(g["final"]):
+        assert gen.token_state(i) == (lu, ru, bool(en))
+    root = next(i for i, x in enumerate(toks) if x["size"] == 1)
+    with pytest.raises(A.TokannealError):
+        gen.SimulateStep(root)  # single code points never move (TokenGenerator.cpp:35-39)
+
+
+def _calc_score(s, pref):
+    """TokenGenerator::CalcScore through the ORACLE's restatement (oracle/dag_oracle.c)."""
+    from test_dag_oracle import Lomax, _lib
+    L = _lib()
+    d = Lomax(0.0, s["moment1"], s["moment2"], s["beta"], s["sigma"])
+    return L.ora_calc_score(C.byref(d), s["raw_score"], s["enabled_cnt"], s["tot_cand"], pref)
+
+
+def test_worker_tasks_follow_the_reference_step_by_step(trace, golden_bin):
+    _, toks = A.ReadTokens(golden_bin)
+    gen = A.TokenGenerator(toks, trace["pref"], trace["batch"])
+    gen.seed(trace["seed"])
+    keys = ("gen_cnt", "enabled_cnt", "raw_score", "temp", "moment1", "moment2", "beta", "sigma")
+    assert len(trace["states"]) >= 500
+    for k, want in enumerate(trace["states"]):
+        gen.WorkerTask()
+        got = gen.state().as_dict()
+        assert {x: got[x] for x in keys} == {x: want[x] for x in keys}, "task %d" % k
+        if k % 50 == 0:
+            assert got["score"] == _calc_score(got, trace["pref"])
+    assert got["tot_cand"] == trace["tot_cand"]
+    assert [s.decode("utf-8") for s in gen.GetSolution()] == trace["solution"]
+    b, off = gen.solution_packed()
+    assert len(off) == len(trace["solution"]) + 1 and int(off[-1]) == len(b)
+
+
+def test_generate_single_worker_is_the_same_sequence_of_tasks(trace, golden_bin):
+    # Generate(pass_cnt) = (pass_cnt + 1) x ceil(tot_cand / batch) WorkerTasks (TokenGenerator.cpp:178-183)
+    per_pass = -(-trace["tot_cand"] // trace["batch"])
+    assert per_pass <= len(trace["states"])
+    _, toks = A.ReadTokens(golden_bin)
+    gen = A.TokenGenerator(toks, trace["pref"], trace["batch"])
+    states = gen.Generate(0, threads=1, seed=trace["seed"])
+    assert len(states) == 1
+    want = trace["states"][per_pass - 1]
+    got = states[0].as_dict()
+    for k in ("gen_cnt", "enabled_cnt", "raw_score", "temp", "moment1", "moment2", "beta", "sigma"):
+        assert got[k] == want[k], k
+    assert got["gen_cnt"] == per_pass * trace["batch"]
+
+
+def _enabled(gen, rpar):
+    return [i for i in range(len(rpar)) if rpar[i] != A.NONE and gen.token_state(i)[2]]
+
+
+def test_generate_with_several_workers_keeps_the_books(trace, golden_bin):
+    _, toks = A.ReadTokens(golden_bin)
+    rpar = toks.arrays()[3]
+    gen = A.TokenGenerator(toks, trace["pref"], trace["batch"])
+    states = gen.Generate(3, threads=4, seed=7)
+    assert len(states) == 4
+    per_pass = -(-trace["tot_cand"] // trace["batch"])
+    assert [s.gen_cnt for s in states] == [per_pass * trace["batch"] * (k + 1) for k in range(4)]
+    st = gen.state()
+    assert len(_enabled(gen, rpar)) == st.enabled_cnt
+    sol = gen.GetSolution()
+    assert len(sol) == st.enabled_cnt + int((rpar == A.NONE).sum()) and len(set(sol)) == len(sol)
+    # the pull towards pref_token_count (TokenGenerator.cpp:108-117) holds the count in its neighbourhood
+    assert 0.3 * trace["pref"] < st.enabled_cnt < 3 * trace["pref"]
+
+
+def test_undoing_every_move_restores_the_counts(trace, golden_bin):
+    # `uses` is a function of the enabled set alone (what an enabled descendant claims is taken off
+    # every ancestor up to the next enabled one): taking all moves back, in any order, must leave
+    # every token with its occurrence count and the raw score's bookkeeping at zero
+    _, toks = A.ReadTokens(golden_bin)
+    n = len(toks)
+    _, uses, _, rpar = toks.arrays()
+    gen = A.TokenGenerator(toks, trace["pref"], trace["batch"])
+    gen.Generate(1, threads=1, seed=99)
+    raw = gen.state().raw_score
+    enabled = _enabled(gen, rpar)
+    assert len(enabled) > 20
+    rng = np.random.default_rng(3)
+    for i in rng.permutation(enabled):
+        sim = gen.SimulateStep(int(i))
+        assert gen.ApplyStep(int(i), False) == sim
+        raw -= sim
+    assert raw == 0
+    for i in range(n):
+        assert gen.token_state(i) == (int(uses[i]), int(uses[i]), rpar[i] == A.NONE)

@@ -97,3 +97,35 @@ def test_shard_entries_are_nul_truncated_and_packed():
     for e, r in zip(shard.GetEntries(), raw):
         assert e.text == r["text"].split("\x00")[0].encode("utf-8")
     assert off.dtype == np.uint64 and corpus.dtype == np.uint8
+
+
+def test_metadata_file_scan_and_format(tmp_path):
+    # the bytes below are what the compiled reference wrote for this directory (ref_harness `cands`
+    # on a.json, sub/b.json, an invalid bad.json and a note.txt): MetadataFile.cpp:33-69
+    from tokenizer_amd.files import MetadataFile
+    data = tmp_path / "data"
+    (data / "sub").mkdir(parents=True)
+    shard = json.dumps([{"id": "1", "title": "t", "text": "hello"}])
+    (data / "a.json").write_text(shard)
+    (data / "sub" / "b.json").write_text(shard)
+    (data / "bad.json").write_text("{}")
+    (data / "note.txt").write_text("x")
+    m = MetadataFile(str(data / ".metadata.json"))
+    assert not m.IsValid()  # built, not read (MetadataFile.cpp:73-74)
+    assert [e.path for e in m.GetFiles()] == ["a.json", "sub/b.json"]
+    assert [e.path for e in m.GetFiles(1)] == ["a.json"]
+    assert m.GetRootPath() == os.path.realpath(str(data))
+    want = ('{\n    "version": "0.4.0",\n    "files": [{\n            "path": "a.json"\n        }, {\n'
+            '            "path": "sub/b.json"\n        }]\n}')
+    assert (data / ".metadata.json").read_text() == want
+    again = MetadataFile(str(data / ".metadata.json"))
+    assert again.IsValid() and [e.path for e in again.GetFiles()] == ["a.json", "sub/b.json"]
+    (data / "c.json").write_text(shard)
+    assert len(MetadataFile(str(data / ".metadata.json")).GetFiles()) == 2       # the index is trusted as it is
+    assert len(MetadataFile(str(data / ".metadata.json"), True).GetFiles()) == 3  # rebuild
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    MetadataFile(str(empty / ".metadata.json"))
+    assert (empty / ".metadata.json").read_text() == '{\n    "version": "0.4.0",\n    "files": []\n}'
+    (empty / ".metadata.json").write_text('{"version": "0.3.0", "files": []}')
+    assert not MetadataFile(str(empty / ".metadata.json")).IsValid()  # wrong version: rebuilt

@@ -49,6 +49,9 @@ _SIGNATURES = [
     ("tokscore_score_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("tokscore_score_incremental", C.c_int, [C.c_void_p, _u64p, _u64p, _u64p]),
     ("tokscore_count_occurrences", C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
+    ("tokscore_extract_candidates", C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
+    ("tokscore_candidates_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), _u64p, C.POINTER(C.c_uint32),
+                                           C.POINTER(C.c_uint32)]),
     ("tokscore_tokenize", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, C.c_uint64, _u64p]),
     ("tokscore_get_info", C.c_int, [C.c_void_p, C.POINTER(TokscoreInfo)]),
     ("tokscore_last_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
@@ -176,6 +179,22 @@ class Scorer:
         pos = C.c_uint64()
         self._check(self._lib.tokscore_count_occurrences(self._h, max_cp, _p64(counts), C.byref(pos)))
         return counts, int(pos.value)
+
+    # GetTokens: FileCandidates + Trie::BuildTokens (GetTokens.cpp:21-90, Trie.cpp:81-152), on the GPU
+    def extract_candidates(self, max_cp: int):
+        """-> (chr, uses, l_parent, r_parent, positions): the candidate set of the resident corpus in
+        the reference's token order; feed the arrays to annealing.Tokens.from_arrays."""
+        n = C.c_uint64()
+        pos = C.c_uint64()
+        self._check(self._lib.tokscore_extract_candidates(self._h, max_cp, C.byref(n), C.byref(pos)))
+        chr_ = np.zeros(n.value, dtype=np.uint32)
+        uses = np.zeros(n.value, dtype=np.uint64)
+        lpar = np.zeros(n.value, dtype=np.uint32)
+        rpar = np.zeros(n.value, dtype=np.uint32)
+        u32 = C.POINTER(C.c_uint32)
+        self._check(self._lib.tokscore_candidates_copy(self._h, chr_.ctypes.data_as(u32), _p64(uses), lpar.ctypes.data_as(u32),
+                                                       rpar.ctypes.data_as(u32)))
+        return chr_, uses, lpar, rpar, int(pos.value)
 
     # SolutionFile::Tokenize (SolutionFile.cpp:83-100); -1 stands for (size_t)-1
     def tokenize(self, text: bytes):

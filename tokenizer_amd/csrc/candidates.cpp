@@ -1,0 +1,305 @@
+// candidates.cpp -- see candidates.h.  Host code, no GPU involved.
+#include "candidates.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+namespace tokanneal {
+
+namespace {
+
+const char kVersion[] = "0.4.0"; // src/config.h:3; written with its terminating NUL (Token.cpp:166-167)
+
+// utf8::internal::sequence_length (utf8/core.h:134-147); 0 = not a lead byte
+inline int SeqLen(uint8_t lead) {
+	if (lead < 0x80) return 1;
+	if ((lead >> 5) == 0x6) return 2;
+	if ((lead >> 4) == 0xe) return 3;
+	if ((lead >> 3) == 0x1e) return 4;
+	return 0;
+}
+
+// utf8::unchecked::next (utf8/unchecked.h:104-131) with the read clipped at `end` (the reference
+// reads past the end of a truncated sequence: undefined there, zeros here)
+inline uint32_t NextCp(const uint8_t *&p, const uint8_t *end) {
+	auto at = [&](int k) -> uint32_t { return p + k < end ? p[k] : 0u; };
+	uint32_t cp = p[0];
+	switch (SeqLen(p[0])) {
+	case 2:
+		cp = ((cp << 6) & 0x7ff) + (at(1) & 0x3f);
+		p += 1;
+		break;
+	case 3:
+		cp = ((cp << 12) & 0xffff) + ((at(1) << 6) & 0xfff) + (at(2) & 0x3f);
+		p += 2;
+		break;
+	case 4:
+		cp = ((cp << 18) & 0x1fffff) + ((at(1) << 12) & 0x3ffff) + ((at(2) << 6) & 0xfff) + (at(3) & 0x3f);
+		p += 3;
+		break;
+	default:
+		break;
+	}
+	p += 1;
+	if (p > end) p = end;
+	return cp;
+}
+
+// Counting trie keyed by (parent node, code point) in one open-addressing table; node 0 is the
+// root.  Replaces the reference's pointer trie with sorted child vectors (Trie.h:20-37): the
+// order of children is restored once, after counting.
+struct CountTrie {
+	std::vector<uint32_t> parent{0}, chr{0};
+	std::vector<uint64_t> freq{0};
+	std::vector<uint32_t> table; // node id, 0 = empty
+	uint64_t mask = 0;
+
+	CountTrie() { Rehash(1u << 16); }
+	static uint64_t Hash(uint32_t p, uint32_t c) {
+		uint64_t x = ((uint64_t)p << 32 | c) * 0x9E3779B97F4A7C15ull;
+		return x ^ (x >> 29);
+	}
+	void Rehash(uint64_t cap) {
+		table.assign(cap, 0);
+		mask = cap - 1;
+		for (uint32_t n = 1; n < parent.size(); n++) {
+			uint64_t h = Hash(parent[n], chr[n]) & mask;
+			while (table[h]) h = (h + 1) & mask;
+			table[h] = n;
+		}
+	}
+	uint32_t Find(uint32_t p, uint32_t c) const {
+		uint64_t h = Hash(p, c) & mask;
+		for (uint32_t n; (n = table[h]) != 0; h = (h + 1) & mask)
+			if (parent[n] == p && chr[n] == c) return n;
+		return 0;
+	}
+	uint32_t FindOrAdd(uint32_t p, uint32_t c) {
+		uint64_t h = Hash(p, c) & mask;
+		for (uint32_t n; (n = table[h]) != 0; h = (h + 1) & mask)
+			if (parent[n] == p && chr[n] == c) return n;
+		const uint32_t n = (uint32_t)parent.size();
+		parent.push_back(p), chr.push_back(c), freq.push_back(0);
+		table[h] = n;
+		if ((uint64_t)n * 2 > mask) Rehash((mask + 1) * 2);
+		return n;
+	}
+};
+
+} // namespace
+
+void AppendUtf8(uint32_t cp, std::string *s) {
+	if (cp < 0x80) {
+		s->push_back((char)cp);
+	} else if (cp < 0x800) {
+		s->push_back((char)((cp >> 6) | 0xc0));
+		s->push_back((char)((cp & 0x3f) | 0x80));
+	} else if (cp < 0x10000) {
+		s->push_back((char)((cp >> 12) | 0xe0));
+		s->push_back((char)(((cp >> 6) & 0x3f) | 0x80));
+		s->push_back((char)((cp & 0x3f) | 0x80));
+	} else {
+		s->push_back((char)((cp >> 18) | 0xf0));
+		s->push_back((char)(((cp >> 12) & 0x3f) | 0x80));
+		s->push_back((char)(((cp >> 6) & 0x3f) | 0x80));
+		s->push_back((char)((cp & 0x3f) | 0x80));
+	}
+}
+
+size_t CandidateSet::TokenSize(size_t i) const {
+	size_t len = 1;
+	for (uint32_t p = rpar[i]; p != kNone; p = rpar[p]) len++;
+	return len;
+}
+
+std::string CandidateSet::GetName(size_t i) const {
+	std::string s;
+	AppendUtf8(chr[i], &s);
+	for (uint32_t p = lpar[i]; p != kNone; p = lpar[p]) AppendUtf8(chr[p], &s);
+	return s;
+}
+
+bool CandidateSet::Validate(std::string *why) const {
+	const size_t n = size();
+	if (uses.size() != n || lpar.size() != n || rpar.size() != n) {
+		if (why) *why = "arrays of different length";
+		return false;
+	}
+	// each chain (l and r) has to end: walk every token once, a walk that meets itself is a cycle
+	for (int side = 0; side < 2; side++) {
+		const std::vector<uint32_t> &par = side ? rpar : lpar;
+		std::vector<uint8_t> state(n, 0); // 0 new, 1 on the current walk, 2 known to end
+		std::vector<uint32_t> path;
+		for (size_t i = 0; i < n; i++) {
+			path.clear();
+			uint32_t v = (uint32_t)i;
+			while (v != kNone && state[v] == 0) {
+				state[v] = 1;
+				path.push_back(v);
+				v = par[v];
+				if (v != kNone && v >= n) {
+					if (why) *why = "parent index out of range";
+					return false;
+				}
+			}
+			if (v != kNone && state[v] == 1) {
+				if (why) *why = "parent chain does not end";
+				return false;
+			}
+			for (uint32_t u : path) state[u] = 2;
+		}
+	}
+	return true;
+}
+
+void BuildCandidates(const uint8_t *bytes, const uint64_t *off, uint64_t n_docs, uint32_t max_cp, CandidateSet *out) {
+	out->clear();
+	CountTrie t;
+	std::vector<uint32_t> cps;
+	for (uint64_t d = 0; d < n_docs; d++) {
+		// ExtractCandidates (GetTokens.cpp:21-27): utf8to32, then one AddString per position
+		cps.clear();
+		const uint8_t *p = bytes + off[d], *end = bytes + off[d + 1];
+		while (p < end) cps.push_back(NextCp(p, end));
+		const size_t n = cps.size();
+		for (size_t i = 0; i < n; i++) {
+			const size_t len = std::min<size_t>(n - i, max_cp);
+			uint32_t node = 0;
+			t.freq[0]++; // Trie.cpp:117
+			for (size_t k = 0; k < len; k++) {
+				node = t.FindOrAdd(node, cps[i + k]);
+				t.freq[node]++; // Trie.cpp:122
+			}
+		}
+	}
+	const uint32_t nodes = (uint32_t)t.parent.size();
+	if (nodes <= 1) return;
+	// children of every node, ascending code point (the order FindChild/CreateChild keep, Trie.cpp:16-37)
+	std::vector<uint32_t> first(nodes + 1, 0), kids(nodes - 1);
+	for (uint32_t n = 1; n < nodes; n++) first[t.parent[n] + 1]++;
+	for (uint32_t n = 0; n < nodes; n++) first[n + 1] += first[n];
+	{
+		std::vector<uint32_t> fill(first.begin(), first.end() - 1);
+		for (uint32_t n = 1; n < nodes; n++) kids[fill[t.parent[n]]++] = n;
+	}
+	for (uint32_t n = 0; n < nodes; n++)
+		std::sort(kids.begin() + first[n], kids.begin() + first[n + 1],
+		          [&](uint32_t a, uint32_t b) { return t.chr[a] < t.chr[b]; });
+	// BuildToken (Trie.cpp:81-91): pre-order, one Token per node, chr = first code point of the string
+	const size_t n_tok = nodes - 1;
+	out->chr.resize(n_tok), out->uses.resize(n_tok), out->lpar.resize(n_tok), out->rpar.resize(n_tok);
+	std::vector<uint32_t> index(nodes, kNone), suffix(nodes, 0), stack;
+	for (uint32_t k = first[1]; k-- > first[0];) stack.push_back(kids[k]);
+	uint32_t next = 0;
+	while (!stack.empty()) {
+		const uint32_t n = stack.back();
+		stack.pop_back();
+		const uint32_t par = t.parent[n];
+		index[n] = next;
+		out->chr[next] = par == 0 ? t.chr[n] : out->chr[index[par]];
+		out->uses[next] = t.freq[n];
+		out->rpar[next] = par == 0 ? kNone : index[par]; // Trie.cpp:98
+		// CompParents walks the suffix down in step (Trie.cpp:94-96): suffix(n) = suffix(parent) + chr
+		suffix[n] = par == 0 ? 0 : t.Find(suffix[par], t.chr[n]);
+		next++;
+		for (uint32_t k = first[n + 1]; k-- > first[n];) stack.push_back(kids[k]);
+	}
+	for (uint32_t n = 1; n < nodes; n++) out->lpar[index[n]] = suffix[n] == 0 ? kNone : index[suffix[n]]; // Trie.cpp:99
+}
+
+bool WriteCandidates(const CandidateSet &c, const std::string &path, std::string *why) {
+	const size_t n = c.size();
+	for (size_t i = 0; i < n; i++)
+		if (c.uses[i] == 0) {
+			if (why) *why = "token " + std::to_string(i) + " has no uses: the format cannot hold it";
+			return false;
+		}
+	FILE *f = fopen(path.c_str(), "wb");
+	if (!f) {
+		if (why) *why = "cannot open " + path;
+		return false;
+	}
+	std::string buf;
+	buf.append(kVersion, sizeof kVersion); // with the NUL
+	const uint64_t cnt = n;
+	buf.append((const char *)&cnt, sizeof cnt);
+	bool ok = true;
+	auto flush = [&](bool force) {
+		if (ok && (force || buf.size() > (1u << 20))) {
+			ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+			buf.clear();
+		}
+	};
+	for (size_t i = 0; i < n; i++) {
+		AppendUtf8(c.chr[i], &buf);
+		for (uint64_t v = c.uses[i]; v;) { // Token.cpp:177-183
+			uint8_t b = v & 0x7F;
+			v >>= 7;
+			if (v) b |= 0x80;
+			buf.push_back((char)b);
+		}
+		flush(false);
+	}
+	for (size_t i = 0; i < n; i++) {
+		const uint32_t lr[2] = {c.lpar[i], c.rpar[i]};
+		buf.append((const char *)lr, sizeof lr);
+		flush(false);
+	}
+	flush(true);
+	ok = (fclose(f) == 0) && ok;
+	if (!ok && why) *why = "write to " + path + " failed";
+	return ok;
+}
+
+ReadCode ReadCandidates(const std::string &path, CandidateSet *out) {
+	FILE *f = fopen(path.c_str(), "rb");
+	if (!f) return READ_BAD_STREAM;
+	std::vector<uint8_t> data;
+	{
+		uint8_t tmp[1 << 16];
+		size_t got;
+		while ((got = fread(tmp, 1, sizeof tmp, f)) > 0) data.insert(data.end(), tmp, tmp + got);
+	}
+	fclose(f);
+	const uint8_t *p = data.data(), *end = p + data.size();
+	if ((size_t)(end - p) < sizeof kVersion || memcmp(p, kVersion, sizeof kVersion) != 0) return READ_INVALID_VERSION;
+	p += sizeof kVersion;
+	out->clear(); // from here on the output is overwritten (Token.h:26-27)
+	uint64_t n = 0;
+	if ((size_t)(end - p) < sizeof n) return READ_BAD_FILE;
+	memcpy(&n, p, sizeof n);
+	p += sizeof n;
+	if (n == 0) return READ_OK; // Token.cpp:121 (trailing bytes are not looked at)
+	if (n >= kNone || n > (uint64_t)(end - p)) return READ_BAD_FILE; // a token takes 2 bytes at least
+	out->chr.reserve(n), out->uses.reserve(n);
+	for (uint64_t i = 0; i < n; i++) {
+		if (p >= end) return READ_BAD_FILE;
+		const int len = std::max(1, SeqLen(*p));
+		if (end - p < len) return READ_BAD_FILE;
+		out->chr.push_back(NextCp(p, end));
+		uint64_t uses = 0;
+		int sft = 0;
+		uint8_t byte;
+		do {
+			if (p >= end || sft > 63) return READ_BAD_FILE;
+			byte = *p++;
+			uses |= (uint64_t)(byte & 0x7F) << sft;
+			sft += 7;
+		} while (byte & 0x80);
+		out->uses.push_back(uses);
+	}
+	if ((uint64_t)(end - p) < n * 8) return READ_BAD_FILE;
+	out->lpar.resize(n), out->rpar.resize(n);
+	for (uint64_t i = 0; i < n; i++) {
+		memcpy(&out->lpar[i], p, 4);
+		memcpy(&out->rpar[i], p + 4, 4);
+		p += 8;
+	}
+	if (p != end) return READ_NOT_DONE; // Token.cpp:159
+	if (!out->Validate(nullptr)) return READ_BAD_FILE;
+	return READ_OK;
+}
+
+} // namespace tokanneal

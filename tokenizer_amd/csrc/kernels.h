@@ -1,5 +1,6 @@
 // kernels.h -- launch entry points of the gfx950 kernels (host-callable wrappers).
 #pragma once
+#include <string>
 
 #include "device_common.h"
 
@@ -87,5 +88,18 @@ uint32_t count_tiles(uint64_t total_bytes);
 // (n_ids + 1 columns; the last one = code-point positions, written by the first pass).
 void launch_count_all(const TrieDev &T, const CorpusDev &C, const CountPlan &plan, uint32_t max_cp, uint32_t n_ids,
                       uint32_t blocks, uint32_t *tile_counters, uint32_t *slab, hipStream_t stream);
+
+// kernels_extract.hip (row f3): the candidate set of the resident corpus, arrays in device memory
+constexpr uint32_t kExtractMaxCp = 32;
+struct CandidateArraysDev {
+	uint32_t *chr = nullptr;  // first code point of the string (Trie.cpp:81-89)
+	uint64_t *uses = nullptr; // occurrences (Trie.cpp:82)
+	uint32_t *lpar = nullptr, *rpar = nullptr;
+	uint64_t n = 0;           // tokens
+	uint64_t positions = 0;   // code points in the corpus (the trie root's freq)
+};
+// 0 ok, 1 HIP error, 2 input outside what the kernels take (message in *err)
+int extract_candidates(const CorpusDev &C, uint32_t max_cp, CandidateArraysDev *out, std::string *err, hipStream_t stream);
+void free_candidates(CandidateArraysDev *c);
 
 } // namespace tokscore

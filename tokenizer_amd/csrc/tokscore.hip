@@ -113,6 +113,7 @@ struct tokscore_ctx {
 	// values of the pending toggles, so that neither copy stalls the host
 	uint64_t *h_out = nullptr;
 	uint64_t *h_patch = nullptr;
+	CandidateArraysDev cands; // result of the last tokscore_extract_candidates, until copied out
 	bool patch_in_flight = false; // h_patch may still be read by a copy nobody waited for
 	float last_ms[4] = {0, 0, 0, 0};
 	bool timing_pending = false;
@@ -133,6 +134,7 @@ int fail(tokscore_ctx *c, int status, const std::string &msg) {
 	} while (0)
 
 void free_corpus(tokscore_ctx *c) {
+	free_candidates(&c->cands);
 	if (c->own_corpus) {
 		if (c->d_bytes) (void)hipFree(c->d_bytes);
 		if (c->d_off) (void)hipFree(c->d_off);
@@ -881,6 +883,40 @@ int tokscore_count_occurrences(tokscore_ctx *c, uint32_t max_cp, uint64_t *count
 	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("count_occurrences: ") + hipGetErrorString(e));
 	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
 	if (positions) *positions = host[c->V + 3];
+	return TOKSCORE_OK;
+}
+
+int tokscore_extract_candidates(tokscore_ctx *c, uint32_t max_cp, uint64_t *n_tokens, uint64_t *positions) {
+	if (!c || !n_tokens) return fail(c, TOKSCORE_E_ARG, "null output");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	if (!c->corpus_set) return fail(c, TOKSCORE_E_STATE, "corpus not set");
+	(void)hipSetDevice(c->device);
+	free_candidates(&c->cands);
+	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+	std::string err;
+	const int rc = extract_candidates(C, max_cp, &c->cands, &err, c->stream);
+	if (rc == 1) return fail(c, TOKSCORE_E_HIP, err);
+	if (rc == 2) return fail(c, TOKSCORE_E_CAPACITY, err);
+	*n_tokens = c->cands.n;
+	if (positions) *positions = c->cands.positions;
+	return TOKSCORE_OK;
+}
+
+int tokscore_candidates_copy(tokscore_ctx *c, uint32_t *chr, uint64_t *uses, uint32_t *lpar, uint32_t *rpar) {
+	if (!c) return fail(c, TOKSCORE_E_ARG, "null context");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	const uint64_t n = c->cands.n;
+	hipError_t e = hipSuccess;
+	if (n) {
+		if (chr) e = hipMemcpyAsync(chr, c->cands.chr, n * sizeof *chr, hipMemcpyDeviceToHost, c->stream);
+		if (e == hipSuccess && uses) e = hipMemcpyAsync(uses, c->cands.uses, n * sizeof *uses, hipMemcpyDeviceToHost, c->stream);
+		if (e == hipSuccess && lpar) e = hipMemcpyAsync(lpar, c->cands.lpar, n * sizeof *lpar, hipMemcpyDeviceToHost, c->stream);
+		if (e == hipSuccess && rpar) e = hipMemcpyAsync(rpar, c->cands.rpar, n * sizeof *rpar, hipMemcpyDeviceToHost, c->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	}
+	free_candidates(&c->cands);
+	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("candidates_copy: ") + hipGetErrorString(e));
 	return TOKSCORE_OK;
 }
 

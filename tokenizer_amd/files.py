@@ -3,6 +3,8 @@
     SolutionFile  -- /root/reference/src/files/SolutionFile.{h,cpp}: the vocabulary
                      (`.tokens.json`), its id assignment, GetId / GetToken / Tokenize
     DataFile      -- /root/reference/src/files/DataFile.{h,cpp}: one corpus shard
+    MetadataFile  -- /root/reference/src/files/MetadataFile.{h,cpp}: the corpus index
+                     (`.metadata.json`), rebuilt by a directory scan when missing or invalid
     score_shard   -- /root/reference/src/main.cpp:31-46: the scoring loop over a shard
 
 Same names, argument meaning and error behaviour as the reference: a file that cannot be
@@ -11,6 +13,7 @@ read or does not validate leaves the object with IsValid() == False, nothing is 
 (libtokscore.so); there is no CPU path in here.
 """
 import json
+import os
 
 import numpy as np
 
@@ -188,6 +191,75 @@ class DataFile:
             off[1:] = np.cumsum([len(t) for t in texts], dtype=np.uint64)
         corpus = np.frombuffer(b"".join(texts), dtype=np.uint8) if off[-1] else np.zeros(0, dtype=np.uint8)
         return corpus, off
+
+
+class MetadataFile:
+    """`.metadata.json` = {"version", "files": [{"path"}]} next to the shards (MetadataFile.cpp:17-75).
+    MetadataFile(path, rebuild=False): read and validate; when the file is missing, invalid or
+    rebuild is set, every `*.json` below the file's directory that is a valid DataFile is listed
+    (paths relative to that directory) and the file is written.  The reference lists them in
+    thread-completion order (MetadataFile.cpp:46-62, not deterministic); here they are sorted."""
+
+    class Entry:
+        __slots__ = ("path",)
+
+        def __init__(self, path):
+            self.path = path
+
+    def __init__(self, path, rebuild: bool = False):
+        self.path_ = path
+        self.modified_ = False
+        doc = None if rebuild else _load_json(path)  # JsonFile(path, rebuild) (JsonFile.cpp:14-29)
+        self.valid_ = self._validate(doc)
+        if self.valid_:
+            self._files = [e["path"] for e in doc["files"]]
+        else:
+            self._build_doc()
+
+    @staticmethod
+    def _validate(doc) -> bool:  # MetadataFile.cpp:17-31
+        if not isinstance(doc, dict):
+            return False
+        if not isinstance(doc.get("version"), str) or doc["version"] != BUILD_VERSION:
+            return False
+        if not isinstance(doc.get("files"), list):
+            return False
+        return all(isinstance(e, dict) and isinstance(e.get("path"), str) for e in doc["files"])
+
+    def _build_doc(self):  # MetadataFile.cpp:33-69 + JsonFile::Save (JsonFile.cpp:35-46)
+        self.modified_ = True
+        root = self.GetRootPath()
+        found = []
+        for base, _, names in os.walk(root):
+            for name in names:
+                full = os.path.join(base, name)
+                if os.path.splitext(name)[1] != ".json" or not os.path.isfile(full):
+                    continue
+                if DataFile(full).IsValid():
+                    found.append(os.path.relpath(full, root))
+        self._files = sorted(found)
+        # PrettyWriter with kFormatSingleLineArray: the array stays on one line, the objects in it do not
+        objs = ", ".join('{\n            "path": %s\n        }' % _json_string(p) for p in self._files)
+        body = "[%s]" % objs
+        text = '{\n    "version": %s,\n    "files": %s\n}' % (_json_string(BUILD_VERSION), body)
+        with open(self.path_, "wb") as f:
+            f.write(text.encode("utf-8"))
+
+    def IsValid(self) -> bool:
+        # (as in the reference, a rebuilt file leaves valid_ false: MetadataFile.cpp:73-74)
+        return self.valid_
+
+    def GetRootPath(self) -> str:  # MetadataFile.cpp:77-79
+        return os.path.realpath(os.path.dirname(os.path.abspath(self.path_)))
+
+    def GetFiles(self, file_cnt: int = -1):  # MetadataFile.cpp:80-87
+        files = []
+        for p in self._files:
+            files.append(MetadataFile.Entry(p))
+            file_cnt -= 1
+            if file_cnt == 0:
+                break
+        return files
 
 
 def score_shard(solution: SolutionFile, shard: DataFile):
