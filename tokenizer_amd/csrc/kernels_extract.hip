@@ -109,41 +109,77 @@ __global__ void doc_rank_kernel(const uint32_t *S, uint32_t N, const uint64_t *o
 	doc_rank[d] = lo;
 }
 
-// len[r]: code points from r to the end of r's document, capped at max_cp (GetTokens.cpp:25)
-__global__ void window_len_kernel(const uint32_t *S, uint32_t N, const uint64_t *off, uint64_t D, const uint32_t *doc_rank,
-                                  uint32_t max_cp, uint8_t *len) {
+// win[r] = position:32 | window bytes:16 | window code points:8 -- everything the later stages need
+// to know about window r in one 8-byte read (they visit the windows in sorted, i.e. random, order).
+// Code points: from r to the end of r's document, capped at max_cp (GetTokens.cpp:25).
+// *max_bytes: the longest window in bytes (how many key words the sort needs).
+__device__ __forceinline__ uint32_t win_pos(uint64_t rec) { return (uint32_t)rec; }
+__device__ __forceinline__ uint32_t win_bytes(uint64_t rec) { return (uint32_t)(rec >> 32) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t win_cps(uint64_t rec) { return (uint32_t)(rec >> 48) & 0xFFu; }
+
+__global__ __launch_bounds__(kThreads) void window_len_kernel(const uint32_t *S, uint32_t N, const uint64_t *off, uint64_t D,
+                                                               const uint32_t *doc_rank, uint32_t max_cp, uint64_t *win,
+                                                               uint32_t *max_bytes) {
 	const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (r >= N) return;
-	const uint64_t p = S[r];
-	uint64_t lo = 0, hi = D; // the document that holds p: last d with off[d] <= p
-	while (lo + 1 < hi) {
-		const uint64_t mid = lo + (hi - lo) / 2;
-		if (off[mid] <= p) lo = mid;
-		else hi = mid;
+	// the document of the block's first code point by bisection (last d with off[d] <= p); the
+	// other lanes walk on from there (a block of 256 code points rarely spans more than two)
+	__shared__ uint64_t first_doc;
+	if (threadIdx.x == 0) {
+		const uint64_t p = S[(uint64_t)blockIdx.x * blockDim.x];
+		uint64_t lo = 0, hi = D;
+		while (lo + 1 < hi) {
+			const uint64_t mid = lo + (hi - lo) / 2;
+			if (off[mid] <= p) lo = mid;
+			else hi = mid;
+		}
+		first_doc = lo;
 	}
-	const uint32_t left = doc_rank[lo + 1] - (uint32_t)r;
-	len[r] = (uint8_t)(left < max_cp ? left : max_cp);
+	__syncthreads();
+	uint32_t nbytes = 0;
+	if (r < N) {
+		const uint64_t p = S[r];
+		uint64_t d = first_doc;
+		while (d + 1 < D && off[d + 1] <= p) d++;
+		const uint32_t left = doc_rank[d + 1] - (uint32_t)r;
+		const uint32_t n = left < max_cp ? left : max_cp;
+		nbytes = S[r + n] - S[r];
+		win[r] = (uint64_t)S[r] | (uint64_t)nbytes << 32 | (uint64_t)n << 48;
+	}
+	__shared__ uint32_t red[kThreads];
+	red[threadIdx.x] = nbytes;
+	__syncthreads();
+	for (int s = kThreads / 2; s > 0; s >>= 1) {
+		if ((int)threadIdx.x < s && red[threadIdx.x + s] > red[threadIdx.x]) red[threadIdx.x] = red[threadIdx.x + s];
+		__syncthreads();
+	}
+	// (one word cannot take an atomic per block of a large grid: most blocks see they have nothing to add)
+	if (threadIdx.x == 0 && red[0] > *(volatile uint32_t *)max_bytes) atomicMax(max_bytes, red[0]);
 }
 
 // ---- 2. sort --------------------------------------------------------------------------------
 
-// word w of window r: bytes [S[r] + 8w, S[r] + 8w + 8) clipped at the window end, big endian, zero padded
-__device__ __forceinline__ uint64_t window_word(const uint8_t *bytes, const uint32_t *S, const uint8_t *len, uint32_t r,
-                                                uint32_t w) {
-	const uint64_t begin = (uint64_t)S[r] + 8ull * w;
-	const uint64_t end = S[r + len[r]]; // S[N] = total
-	uint64_t key = 0;
-	for (uint32_t k = 0; k < 8; k++) {
-		const uint64_t p = begin + k;
-		key = (key << 8) | (p < end ? bytes[p] : 0);
-	}
+// word w of a window: its bytes [8w, 8w + 8) clipped at the window end, big endian, zero padded.
+// Two aligned 8-byte loads and a funnel shift (the corpus buffer is 256-byte aligned and readable
+// past its end).
+__device__ __forceinline__ uint64_t window_word(const uint8_t *bytes, uint64_t rec, uint32_t w) {
+	const uint32_t n = win_bytes(rec);
+	if (8 * w >= n) return 0;
+	const uint64_t begin = (uint64_t)win_pos(rec) + 8ull * w;
+	const uint64_t *q = (const uint64_t *)(bytes + (begin & ~7ull));
+	const uint32_t sh = (uint32_t)(begin & 7) * 8;
+	const uint64_t lo = q[0];
+	uint64_t v = lo;
+	if (sh) v = (lo >> sh) | (q[1] << (64 - sh));
+	uint64_t key = __builtin_bswap64(v); // byte k of the word at bits 63-8k
+	const uint32_t valid = n - 8 * w;
+	if (valid < 8) key &= ~0ull << (8 * (8 - valid));
 	return key;
 }
 
-__global__ void gather_keys_kernel(const uint8_t *bytes, const uint32_t *S, const uint8_t *len, const uint32_t *perm, uint32_t N,
-                                   uint32_t w, uint64_t *keys) {
+__global__ void gather_keys_kernel(const uint8_t *bytes, const uint64_t *win, const uint32_t *perm, uint32_t N, uint32_t w,
+                                   uint64_t *keys) {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < N) keys[i] = window_word(bytes, S, len, perm[i], w);
+	if (i < N) keys[i] = window_word(bytes, win[perm[i]], w);
 }
 
 __global__ void iota_kernel(uint32_t *v, uint32_t N) {
@@ -153,25 +189,58 @@ __global__ void iota_kernel(uint32_t *v, uint32_t N) {
 
 // ---- 3. lcp ---------------------------------------------------------------------------------
 
-// common code points of sorted windows i-1 and i; slen[i] = len of sorted window i; inv = perm^-1
-__global__ void lcp_kernel(const uint8_t *bytes, const uint32_t *S, const uint8_t *len, const uint32_t *perm, uint32_t N,
-                           uint8_t *lcp, uint8_t *slen, uint32_t *inv, uint32_t *fresh) {
+// common code points of sorted windows i-1 and i; slen[i] = code points of sorted window i;
+// inv = perm^-1; srec[i] = the window record in sorted order.  Every lane fetches its own window
+// once (record + key words) and leaves it in LDS for the lane after it; only the first lane of a
+// block fetches its predecessor itself.  Dynamic LDS: (words + 1) * blockDim.x * 8 bytes.
+__global__ __launch_bounds__(kThreads) void lcp_kernel(const uint8_t *bytes, const uint64_t *win, const uint32_t *perm, uint32_t N,
+                                                        uint32_t words, uint8_t *lcp, uint8_t *slen, uint32_t *inv, uint32_t *fresh,
+                                                        uint64_t *srec) {
+	extern __shared__ uint64_t tile[]; // [0 .. words) rows of key words, row `words` = records
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t t = threadIdx.x;
+	uint64_t rb = 0;
+	if (i < N) {
+		const uint32_t b = perm[i];
+		rb = win[b];
+		inv[b] = (uint32_t)i;
+		srec[i] = rb;
+		for (uint32_t w = 0; w < words; w++) tile[w * kThreads + t] = window_word(bytes, rb, w);
+	}
+	tile[words * kThreads + t] = rb;
+	__syncthreads();
 	if (i >= N) return;
-	const uint32_t b = perm[i];
-	const uint32_t lb = len[b];
-	inv[b] = (uint32_t)i;
+	const uint32_t lb = win_cps(rb), nb = win_bytes(rb);
 	slen[i] = (uint8_t)lb;
 	uint32_t common = 0;
 	if (i > 0) {
-		const uint32_t a = perm[i - 1];
-		const uint32_t pa = S[a], pb = S[b];
-		const uint32_t na = S[a + len[a]] - pa, nb = S[b + lb] - pb;
+		const uint64_t ra = t ? tile[words * kThreads + t - 1] : win[perm[i - 1]];
+		const uint32_t na = win_bytes(ra);
 		const uint32_t n = na < nb ? na : nb;
-		uint32_t same = 0;
-		while (same < n && bytes[pa + same] == bytes[pb + same]) same++;
-		// whole code points of window b inside the common bytes
-		while (common < lb && S[b + common + 1] - pb <= same) common++;
+		// common bytes, a word at a time (a window that ended reads as zeros, a document holds no zero byte)
+		uint32_t same = n;
+		for (uint32_t w = 0; 8 * w < n; w++) {
+			const uint64_t A = t ? tile[w * kThreads + t - 1] : window_word(bytes, ra, w);
+			const uint64_t x = A ^ tile[w * kThreads + t];
+			if (x) {
+				const uint32_t at = 8 * w + (uint32_t)(__builtin_clzll(x) >> 3);
+				same = at < n ? at : n;
+				break;
+			}
+		}
+		// whole code points of window b inside them: offsets 1 .. same where a code point starts
+		// (the zero byte after the window's end counts as one: the last code point ended there)
+		for (uint32_t w = 0; 8 * w <= same && same > 0; w++) {
+			const uint32_t lo = w == 0 ? 1 : 8 * w, hi = same < 8 * w + 7 ? same : 8 * w + 7;
+			if (lo > hi) continue;
+			const uint64_t B = w < words ? tile[w * kThreads + t] : 0;
+			const uint64_t y = (B ^ 0x8080808080808080ull) & 0xC0C0C0C0C0C0C0C0ull; // zero byte = continuation byte
+			const uint64_t starts = (y | (y >> 1)) & 0x4040404040404040ull;
+			const uint32_t qlo = lo - 8 * w, qhi = hi - 8 * w; // byte 0 is the most significant
+			const uint64_t sel = (~0ull >> (8 * qlo)) & (~0ull << (8 * (7 - qhi)));
+			common += (uint32_t)__builtin_popcountll(starts & sel);
+		}
+		if (common > lb) common = lb;
 	}
 	lcp[i] = (uint8_t)common;
 	fresh[i] = lb - common; // trie nodes this window adds
@@ -217,7 +286,7 @@ __device__ __forceinline__ uint32_t first_cp(const uint8_t *p) { // utf8::unchec
 	return cp;
 }
 
-__global__ void fill_tokens_kernel(const uint8_t *bytes, const uint32_t *S, const uint32_t *perm, const uint32_t *inv,
+__global__ void fill_tokens_kernel(const uint8_t *bytes, const uint64_t *srec, const uint32_t *perm, const uint32_t *inv,
                                    const uint32_t *run, const uint8_t *lcp, const uint8_t *slen, const uint64_t *base, uint32_t N,
                                    uint32_t *chr, uint32_t *lpar, uint32_t *rpar) {
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -225,7 +294,7 @@ __global__ void fill_tokens_kernel(const uint8_t *bytes, const uint32_t *S, cons
 	const uint32_t l = lcp[i], n = slen[i];
 	if (l >= n) return;
 	const uint32_t r = perm[i];
-	const uint32_t cp = first_cp(bytes + S[r]); // BuildToken hands the FIRST code point down (Trie.cpp:81-89)
+	const uint32_t cp = first_cp(bytes + win_pos(srec[i])); // BuildToken hands the FIRST code point down (Trie.cpp:81-89)
 	// the window one code point on (same document whenever this one has two code points or more)
 	const uint32_t j = n >= 2 ? inv[r + 1] : 0;
 	for (uint32_t d = l + 1; d <= n; d++) {
@@ -308,20 +377,23 @@ int extract_candidates(const CorpusDev &C, uint32_t max_cp, CandidateArraysDev *
 	}
 	if (N == 0) return 0;
 
-	DeviceBuf S, doc_rank, len;
+	DeviceBuf S, doc_rank, win;
 	EX_TRY(S.alloc(((size_t)N + 1) * sizeof(uint32_t)));
 	EX_TRY(doc_rank.alloc((C.D + 1) * sizeof(uint32_t)));
-	EX_TRY(len.alloc((size_t)N + 1));
+	EX_TRY(win.alloc((size_t)N * sizeof(uint64_t)));
 	hipLaunchKernelGGL(fill_starts_kernel, dim3(tiles), dim3(kThreads), 0, stream, C.bytes, C.total, tile_count.as<uint32_t>(),
 	                   S.as<uint32_t>());
 	const uint32_t total32 = (uint32_t)C.total;
 	EX_TRY(hipMemcpyAsync(S.as<uint32_t>() + N, &total32, sizeof total32, hipMemcpyHostToDevice, stream));
-	EX_TRY(hipMemsetAsync(len.as<uint8_t>() + N, 0, 1, stream));
 	hipLaunchKernelGGL(doc_rank_kernel, dim3(blocks_for(C.D + 1)), dim3(kThreads), 0, stream, S.as<uint32_t>(), N, C.off, C.D,
 	                   doc_rank.as<uint32_t>());
+	EX_TRY(hipMemsetAsync(flags.p, 0, sizeof(uint32_t), stream)); // reused: longest window in bytes
 	hipLaunchKernelGGL(window_len_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, stream, S.as<uint32_t>(), N, C.off, C.D,
-	                   doc_rank.as<uint32_t>(), max_cp, len.as<uint8_t>());
-	EX_TRY(hipStreamSynchronize(stream)); // total32 is a stack variable
+	                   doc_rank.as<uint32_t>(), max_cp, win.as<uint64_t>(), flags.as<uint32_t>());
+	uint32_t max_bytes = 0;
+	EX_TRY(hipMemcpyAsync(&max_bytes, flags.p, sizeof max_bytes, hipMemcpyDeviceToHost, stream));
+	EX_TRY(hipStreamSynchronize(stream)); // (total32 is a stack variable, too)
+	(void)hipFree(S.p), S.p = nullptr; // positions live on in the window records
 
 	// 2. sort: least significant word first, every pass stable
 	DeviceBuf keys_a, keys_b, perm_a, perm_b;
@@ -331,12 +403,12 @@ int extract_candidates(const CorpusDev &C, uint32_t max_cp, CandidateArraysDev *
 	EX_TRY(perm_b.alloc((size_t)N * sizeof(uint32_t)));
 	uint32_t *perm = perm_a.as<uint32_t>(), *perm_alt = perm_b.as<uint32_t>();
 	hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, stream, perm, N);
-	const uint32_t words = (4 * max_cp + 7) / 8;
+	const uint32_t words = (max_bytes + 7) / 8; // key words that hold anything: 2 for mostly-ASCII text at max_cp = 10
 	EX_TRY(rocprim::radix_sort_pairs(nullptr, need, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_alt, N, 0, 64, stream));
 	EX_TRY(ensure_temp(need));
 	for (uint32_t w = words; w-- > 0;) {
-		hipLaunchKernelGGL(gather_keys_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, stream, C.bytes, S.as<uint32_t>(),
-		                   len.as<uint8_t>(), perm, N, w, keys_a.as<uint64_t>());
+		hipLaunchKernelGGL(gather_keys_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, stream, C.bytes, win.as<uint64_t>(), perm, N,
+		                   w, keys_a.as<uint64_t>());
 		EX_TRY(rocprim::radix_sort_pairs(temp.p, need, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), perm, perm_alt, N, 0, 64,
 		                                 stream));
 		std::swap(perm, perm_alt);
@@ -345,15 +417,17 @@ int extract_candidates(const CorpusDev &C, uint32_t max_cp, CandidateArraysDev *
 	(void)hipFree(keys_b.p), keys_b.p = nullptr;
 
 	// 3. lcp, token numbering
-	DeviceBuf lcp, slen, inv, fresh, base;
+	DeviceBuf lcp, slen, inv, fresh, base, srec;
+	EX_TRY(srec.alloc((size_t)N * sizeof(uint64_t)));
 	EX_TRY(lcp.alloc(N));
 	EX_TRY(slen.alloc(N));
 	EX_TRY(inv.alloc(((size_t)N + 1) * sizeof(uint32_t)));
 	EX_TRY(fresh.alloc((size_t)N * sizeof(uint32_t)));
 	EX_TRY(base.alloc(((size_t)N + 1) * sizeof(uint64_t)));
 	EX_TRY(hipMemsetAsync(inv.as<uint32_t>() + N, 0, sizeof(uint32_t), stream));
-	hipLaunchKernelGGL(lcp_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, stream, C.bytes, S.as<uint32_t>(), len.as<uint8_t>(), perm,
-	                   N, lcp.as<uint8_t>(), slen.as<uint8_t>(), inv.as<uint32_t>(), fresh.as<uint32_t>());
+	hipLaunchKernelGGL(lcp_kernel, dim3(blocks_for(N)), dim3(kThreads), (words + 1) * kThreads * sizeof(uint64_t), stream, C.bytes,
+	                   win.as<uint64_t>(), perm, N, words, lcp.as<uint8_t>(), slen.as<uint8_t>(), inv.as<uint32_t>(),
+	                   fresh.as<uint32_t>(), srec.as<uint64_t>());
 	EX_TRY(rocprim::exclusive_scan(nullptr, need, fresh.as<uint32_t>(), base.as<uint64_t>(), (uint64_t)0, N, rocprim::plus<uint64_t>(),
 	                               stream));
 	EX_TRY(ensure_temp(need));
@@ -370,6 +444,7 @@ int extract_candidates(const CorpusDev &C, uint32_t max_cp, CandidateArraysDev *
 		return 2;
 	}
 	(void)hipFree(fresh.p), fresh.p = nullptr;
+	(void)hipFree(win.p), win.p = nullptr;
 
 	// 4. runs per depth
 	DeviceBuf run;
@@ -392,7 +467,7 @@ int extract_candidates(const CorpusDev &C, uint32_t max_cp, CandidateArraysDev *
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(run_uses_kernel, dim3(blocks_for((uint64_t)N + 1)), dim3(kThreads), 0, stream, run.as<uint32_t>(),
 		                   lcp.as<uint8_t>(), slen.as<uint8_t>(), base.as<uint64_t>(), N, max_cp, uses);
-		hipLaunchKernelGGL(fill_tokens_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, stream, C.bytes, S.as<uint32_t>(), perm,
+		hipLaunchKernelGGL(fill_tokens_kernel, dim3(blocks_for(N)), dim3(kThreads), 0, stream, C.bytes, srec.as<uint64_t>(), perm,
 		                   inv.as<uint32_t>(), run.as<uint32_t>(), lcp.as<uint8_t>(), slen.as<uint8_t>(), base.as<uint64_t>(), N, chr, lpar,
 		                   rpar);
 		e = hipGetLastError();
