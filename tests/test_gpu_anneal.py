@@ -35,6 +35,11 @@ def test_anneal_then_score_matches_oracle(tmp_path):
                                               threads=1, seed=11)
         assert again.tokens == sol.tokens and tt2 == total_tokens
         again.close()
+        # ... and again with the candidates extracted on the GPU instead of the host
+        gpu, _, tt3, _ = A.anneal_and_score(corpus, off, max_len=6, pref_token_count=800, pass_cnt=3, batch_size=16,
+                                            threads=1, seed=11, gpu_candidates=True)
+        assert gpu.tokens == sol.tokens and tt3 == total_tokens
+        gpu.close()
     finally:
         sol.close()
 

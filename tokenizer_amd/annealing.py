@@ -174,6 +174,19 @@ def GetTokens(corpus: np.ndarray, doc_off: np.ndarray, max_len: int = 255) -> To
     return Tokens(h.value)
 
 
+def GetTokensGpu(corpus: np.ndarray, doc_off: np.ndarray, max_len: int = 255, device: int = 0) -> Tokens:
+    """The same candidate set as GetTokens, computed on the GPU (tokscore_extract_candidates: one
+    sort of all windows instead of a trie; max_len <= 32, valid UTF-8 without NUL bytes)."""
+    from . import Scorer
+    s = Scorer(device)
+    try:
+        s.set_corpus(corpus, doc_off)
+        chr_, uses, lpar, rpar, _ = s.extract_candidates(max_len)
+    finally:
+        s.close()
+    return Tokens.from_arrays(chr_, uses, lpar, rpar)
+
+
 def candidates_file_name(file_cnt=None, max_len: int = 255) -> str:
     """The cache file GetTokens uses under the corpus root (GetTokens.cpp:94-96)."""
     return ".candidates-" + ("all" if file_cnt is None else str(file_cnt)) + ("" if max_len == 255 else "-%d" % max_len) + ".bin"
@@ -268,7 +281,7 @@ class TokenGenerator:
 
 def anneal_and_score(corpus, doc_off, score_corpus=None, score_off=None, max_len=10, pref_token_count=30000,
                      pass_cnt=20, batch_size=None, threads=0, seed=-1, solution_path=None, device=0,
-                     trajectory=None):
+                     trajectory=None, gpu_candidates=False):
     """main.cpp:20-46 end to end: GetTokens(max_len) -> TokenGenerator(pref) -> Generate(pass_cnt)
     -> GetSolution -> SolutionFile(solution, path) -> score of a shard.  The shard that is scored
     defaults to the one the candidates came from.  -> (SolutionFile, counts, total_tokens,
@@ -277,11 +290,12 @@ def anneal_and_score(corpus, doc_off, score_corpus=None, score_off=None, max_len
     trajectory: a list that receives, after every pass, the annealer's own state together with
     what the GPU measures for the solution as it stands ({"pass", "score", "enabled_cnt",
     "total_tokens", "bytes_per_token"}) -- the reference only ever sees its DAG estimate.  The
-    passes then run as pass_cnt + 1 calls of Generate(0) (worker k of pass p seeded seed + p + k)."""
+    passes then run as pass_cnt + 1 calls of Generate(0) (worker k of pass p seeded seed + p + k).
+    gpu_candidates: build the candidate set on the GPU (GetTokensGpu) instead of the host."""
     from . import Scorer
     from .files import SolutionFile
     sc, so = (corpus, doc_off) if score_corpus is None else (score_corpus, score_off)
-    tokens = GetTokens(corpus, doc_off, max_len)
+    tokens = GetTokensGpu(corpus, doc_off, max_len, device) if gpu_candidates else GetTokens(corpus, doc_off, max_len)
     gen = TokenGenerator(tokens, pref_token_count, batch_size)
     if trajectory is None:
         gen.Generate(pass_cnt, threads, seed)
