@@ -312,9 +312,23 @@ static int cmd_trace(int argc, char **argv) {
 	return 0;
 }
 
+// load <shard.json>: DataFile(path) + GetEntries() (JsonFile.cpp:14-29, DataFile.cpp:3-31), timed
+static int cmd_load(int argc, char **argv) {
+	if (argc < 3) return 2;
+	auto t0 = std::chrono::steady_clock::now();
+	DataFile shard(argv[2]);
+	size_t docs = 0, bytes = 0;
+	if (shard.IsValid())
+		for (const DataFile::Entry &e : shard.GetEntries()) docs++, bytes += e.text.size();
+	const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	std::cout << "{\"valid\": " << (shard.IsValid() ? 1 : 0) << ", \"docs\": " << docs << ", \"text_bytes\": " << bytes
+	          << ", \"seconds\": " << secs << "}" << std::endl;
+	return 0;
+}
+
 int main(int argc, char **argv) {
 	if (argc < 2) {
-		std::cerr << "usage: ref_harness score|anneal|dag|cands|trace ..." << std::endl;
+		std::cerr << "usage: ref_harness score|anneal|dag|cands|trace|load ..." << std::endl;
 		return 2;
 	}
 	const std::string cmd = argv[1];
@@ -323,6 +337,7 @@ int main(int argc, char **argv) {
 	if (cmd == "dag") return cmd_dag(argc, argv);
 	if (cmd == "cands") return cmd_cands(argc, argv);
 	if (cmd == "trace") return cmd_trace(argc, argv);
+	if (cmd == "load") return cmd_load(argc, argv);
 	std::cerr << "unknown command " << cmd << std::endl;
 	return 2;
 }

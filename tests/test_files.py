@@ -12,6 +12,8 @@ import pytest
 from tokenizer_amd import files
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
 GOLD = os.path.join(HERE, "golden")
 
 
@@ -129,3 +131,87 @@ def test_metadata_file_scan_and_format(tmp_path):
     assert (empty / ".metadata.json").read_text() == '{\n    "version": "0.4.0",\n    "files": []\n}'
     (empty / ".metadata.json").write_text('{"version": "0.3.0", "files": []}')
     assert not MetadataFile(str(empty / ".metadata.json")).IsValid()  # wrong version: rebuilt
+
+
+# ---- the one-pass C++ shard reader (include/tokfiles.h) against DataFile and the reference's totals ----
+
+def _same_entries(a, b):
+    ea, eb = a.GetEntries(), b.GetEntries()
+    return len(ea) == len(eb) and all((x.id, x.title, x.text) == (y.id, y.title, y.text) for x, y in zip(ea, eb))
+
+
+def test_shard_reader_exports_and_matches_reference_totals(tmp_path):
+    import ctypes as C
+    import re
+    from tokenizer_amd import annealing
+    text = open(os.path.join(ROOT, "include", "tokfiles.h")).read()
+    declared = sorted(set(re.findall(r"\b(tokfiles_[a-z_]+)\s*\(", text)))
+    assert declared == ["tokfiles_shard_bytes", "tokfiles_shard_copy", "tokfiles_shard_docs", "tokfiles_shard_free",
+                        "tokfiles_shard_read"]
+    lib = C.CDLL(annealing.LIB_PATH)
+    assert all(hasattr(lib, n) for n in declared)
+    # every golden shard: the document count and byte total the compiled reference reported
+    for case in sorted(os.listdir(GOLDEN)):
+        d = os.path.join(GOLDEN, case)
+        exp = [p for p in ("expected.json", "expected.json.gz") if os.path.exists(os.path.join(d, p))]
+        if not exp:
+            continue
+        opener = gzip.open if exp[0].endswith(".gz") else open
+        want = json.loads(opener(os.path.join(d, exp[0]), "rb").read().decode("utf-8"))
+        shard = os.path.join(d, "shard.json")
+        if not os.path.exists(shard):
+            shard = str(tmp_path / (case + ".json"))
+            open(shard, "wb").write(gzip.open(os.path.join(d, "shard.json.gz")).read())
+        s = files.ShardFile(shard)
+        assert s.IsValid(), case
+        corpus, off = s.packed()
+        assert (len(off) - 1, int(off[-1])) == (want["docs"], want["total_bytes"]), case
+        assert _same_entries(s, files.DataFile(shard)), case
+
+
+def test_shard_reader_json_details(tmp_path):
+    def both(text, raw=False):
+        p = tmp_path / "s.json"
+        p.write_bytes(text if raw else text.encode("utf-8"))
+        return files.ShardFile(str(p)), files.DataFile(str(p))
+
+    ok = ('[ {"title":"T\\u00e9\\ud834\\udd1e","id":"1","extra":{"a":[1,2.5e3,-0,true,false,null,"x\\"y"],"b":{}},'
+          '"text":"a\\n\\t\\\\\\/\\"b\\u0041\\b\\f\\r"} ,\n {"id":"2","text":"abc\\u0000def","title":"","text":"second text ignored",'
+          '"id":7}, {"\\u0074ext":"escaped key","id":"3","title":"t"} ]  \n')
+    s, d = both(ok)
+    assert s.IsValid() and d.IsValid() and _same_entries(s, d)
+    e = s.GetEntries()
+    assert e[0].text == b'a\n\t\\/"bA\x08\x0c\r' and e[0].title == "Té\U0001d11e".encode("utf-8")
+    assert e[1].text == b"abc" and e[1].id == b"2"          # NUL cut, the first member of a name counts
+    assert e[2].text == b"escaped key"
+    for bad in ['[]', '{}', '[1]', '[{"id":"1","text":"x"}]', '[{"id":1,"text":"x","title":"t"}]',
+                '[{"id":"1","text":"x","title":"t"},]', '[{"id":"1","text":"x","title":"t"}] x',
+                '[{"id":"1","text":"x","title":"t",}]', '[{"id":"1","text":"x\ty","title":"t"}]',
+                '[{"id":"1","text":"\\ud800x","title":"t"}]', '[{"id":"1","text":"\\udc00","title":"t"}]',
+                '[{"id":"1","text":"\\q","title":"t"}]', '[{"id":"1","text":"x","title":"t","n":01}]',
+                '[{"id":"1","text":"x","title":"t","n":1e999}]', '[{"id":"1","text":"x","title":"t"}',
+                '[{"id":"1","text":"x","title":"t","n":tru}]', '[{"id":"1","text":"x","title":"t","n":NaN}]', '', '[{"id":"1" "text":"x","title":"t"}]']:
+        s, d = both(bad)
+        assert not s.IsValid() and len(s.GetEntries()) == 0, bad
+        assert not d.IsValid(), bad
+    s, _ = both(b'[{"id":"1","text":"caf\xe9","title":"t"}]', raw=True)  # rapidjson does not validate UTF-8
+    assert s.IsValid() and s.GetEntries()[0].text == b"caf\xe9"
+    assert not files.ShardFile(str(tmp_path / "missing.json")).IsValid()
+
+
+def test_shard_reader_equals_datafile_on_a_synthetic_shard(tmp_path):
+    from tokenizer_amd import synth
+    corpus, off = synth.cjk_heavy(300_000, seed=9, doc_lo=16, doc_hi=9000)
+    raw = corpus.tobytes()
+    texts = [raw[int(off[i]):int(off[i + 1])].decode("utf-8") for i in range(len(off) - 1)]
+    texts[3] = 'quote " backslash \\ tab \t newline \n bell \x07 \U0001d11e'
+    for ascii_only in (True, False):
+        p = tmp_path / ("a%d.json" % ascii_only)
+        with open(p, "w", encoding="utf-8") as f:
+            json.dump([{"id": str(i), "title": "t%d" % i, "text": t} for i, t in enumerate(texts)], f,
+                      ensure_ascii=ascii_only, indent=2 if ascii_only else None)
+        s, d = files.ShardFile(str(p)), files.DataFile(str(p))
+        assert s.IsValid() and _same_entries(s, d)
+        c2, o2 = s.packed()
+        want = [t.encode("utf-8") for t in texts]
+        assert int(o2[-1]) == sum(len(w) for w in want) and c2.tobytes() == b"".join(want)

@@ -5,6 +5,9 @@
     DataFile      -- /root/reference/src/files/DataFile.{h,cpp}: one corpus shard
     MetadataFile  -- /root/reference/src/files/MetadataFile.{h,cpp}: the corpus index
                      (`.metadata.json`), rebuilt by a directory scan when missing or invalid
+    ShardFile     -- the same shard read by the C++ one-pass reader (include/tokfiles.h,
+                     csrc/shard_reader.cpp): DataFile's verdict and strings, straight into the
+                     packed form, without a DOM
     score_shard   -- /root/reference/src/main.cpp:31-46: the scoring loop over a shard
 
 Same names, argument meaning and error behaviour as the reference: a file that cannot be
@@ -43,10 +46,30 @@ def _json_string(s: str) -> str:
     return "".join(out)
 
 
+def _first_wins(pairs):
+    """rapidjson looks a member up with FindMember: the FIRST one of a repeated name."""
+    d = {}
+    for k, v in pairs:
+        d.setdefault(k, v)
+    return d
+
+
+def _no_constant(name):  # NaN / Infinity are not JSON; rapidjson's default flags reject them
+    raise ValueError(name)
+
+
+def _finite_float(text):  # kParseErrorNumberTooBig: a number that does not fit a double
+    v = float(text)
+    if v in (float("inf"), float("-inf")):
+        raise ValueError(text)
+    return v
+
+
 def _load_json(path):
     try:
         with open(path, "rb") as f:
-            return json.loads(f.read().decode("utf-8"))
+            return json.loads(f.read().decode("utf-8"), object_pairs_hook=_first_wins, parse_constant=_no_constant,
+                              parse_float=_finite_float)
     except (OSError, ValueError):
         return None
 
@@ -260,6 +283,58 @@ class MetadataFile:
             if file_cnt == 0:
                 break
         return files
+
+
+class ShardFile:
+    """DataFile(path) through libtokanneal.so's one-pass reader (tokfiles_shard_read): IsValid(),
+    GetEntries() and packed() as DataFile's, for shards too large to want a JSON DOM of."""
+
+    def __init__(self, path):
+        import ctypes as C
+        from . import annealing
+        lib = annealing.load_library()
+        if not hasattr(lib.tokfiles_shard_read, "_bound"):
+            lib.tokfiles_shard_read.restype = C.c_int
+            lib.tokfiles_shard_read.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.POINTER(C.c_int)]
+            lib.tokfiles_shard_docs.restype = C.c_uint64
+            lib.tokfiles_shard_docs.argtypes = [C.c_void_p]
+            lib.tokfiles_shard_bytes.restype = C.c_uint64
+            lib.tokfiles_shard_bytes.argtypes = [C.c_void_p, C.c_int]
+            lib.tokfiles_shard_copy.restype = C.c_int
+            lib.tokfiles_shard_copy.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
+            lib.tokfiles_shard_free.restype = None
+            lib.tokfiles_shard_free.argtypes = [C.c_void_p]
+            lib.tokfiles_shard_read._bound = True
+        self.path_ = path
+        h = C.c_void_p()
+        valid = C.c_int(0)
+        st = lib.tokfiles_shard_read(C.byref(h), os.fsencode(path), C.byref(valid))
+        if st != 0:
+            raise MemoryError("tokfiles_shard_read: status %d" % st)
+        self.valid_ = bool(valid.value)
+        self._fields = []
+        try:
+            n = int(lib.tokfiles_shard_docs(h))
+            for field in range(3):  # text, id, title
+                b = np.zeros(max(1, int(lib.tokfiles_shard_bytes(h, field))), dtype=np.uint8)
+                off = np.zeros(n + 1, dtype=np.uint64)
+                lib.tokfiles_shard_copy(h, field, b.ctypes.data_as(C.POINTER(C.c_uint8)), off.ctypes.data_as(C.POINTER(C.c_uint64)))
+                self._fields.append((b[:int(off[-1])], off))
+        finally:
+            lib.tokfiles_shard_free(h)
+
+    def IsValid(self) -> bool:
+        return self.valid_
+
+    def packed(self):
+        return self._fields[0]
+
+    def GetEntries(self):
+        cut = []
+        for b, off in self._fields:
+            raw = b.tobytes()
+            cut.append([raw[int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)])
+        return [DataFile.Entry(i, t, x) for x, i, t in zip(*cut)]
 
 
 def score_shard(solution: SolutionFile, shard: DataFile):
