@@ -111,7 +111,7 @@ int tokscore_score_async(tokscore_ctx *ctx, void *d_out, void *stream);
  * trie as it was: subtracted; as it is: added) on top of the previous evaluation's counts,
  * which stay in device memory.  Falls back to a full evaluation by itself when there is no
  * previous evaluation, more than 8 toggles are pending, or the strings occur in more than
- * 1/12 of the chunks; tokscore_info.rescored_chunks reports what the call did. */
+ * 1/3 of the chunks; tokscore_info.rescored_chunks reports what the call did. */
 int tokscore_score_incremental(tokscore_ctx *ctx, uint64_t *counts, uint64_t *total_tokens,
                                uint64_t *total_bytes);
 

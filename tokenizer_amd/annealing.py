@@ -68,6 +68,14 @@ _SIGNATURES = [
     ("tokanneal_solution", C.c_int, [_vp, _u8p, C.c_uint64, _u64p, C.c_uint64, _u64p, _u64p]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
+# include/tokfiles.h (the shard reader lives in the same library; files.ShardFile is its mirror)
+_FILES_SIGNATURES = [
+    ("tokfiles_shard_read", C.c_int, [_vpp, C.c_char_p, C.POINTER(C.c_int)]),
+    ("tokfiles_shard_docs", C.c_uint64, [_vp]),
+    ("tokfiles_shard_bytes", C.c_uint64, [_vp, C.c_int]),
+    ("tokfiles_shard_copy", C.c_int, [_vp, C.c_int, _u8p, _u64p]),
+    ("tokfiles_shard_free", None, [_vp]),
+]
 
 _lib = None
 
@@ -84,7 +92,7 @@ def load_library():
         if not os.path.exists(LIB_PATH):
             raise ImportError("%s is missing: build it with `make -C tokenizer_amd/csrc`" % LIB_PATH)
         lib = C.CDLL(LIB_PATH)
-        for name, res, args in _SIGNATURES:
+        for name, res, args in _SIGNATURES + _FILES_SIGNATURES:
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args

@@ -742,7 +742,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 	// after the pending slot patches, as it is (added) -- on top of the counts the last
 	// evaluation left in d_out.  Same result as tokscore_score, bit for bit; anything that does
 	// not fit the fast path (no previous evaluation, fallback scan path, speculated boundaries,
-	// many toggles, a token that occurs in a third of the chunks) is a plain full evaluation.
+	// many toggles, a token that occurs in more than a third of the chunks) is a plain full evaluation.
 	if (!c || !counts) return fail(c, TOKSCORE_E_ARG, "null output");
 	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
 	(void)hipSetDevice(c->device);
@@ -762,7 +762,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		c->calls++;
 		HIP_TRY(c, hipEventRecord(c->ev[0], s));
 		if (c->index_state == 0) build_index(c);
-		const uint32_t limit = c->nchunks / 12; // beyond this a full evaluation is as fast
+		const uint32_t limit = c->nchunks / (uint32_t)std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)); // beyond this two partial passes cost what a full evaluation does
 		if (c->index_state == 1) {
 			// the index knows the chunks (and how many) without a search or a host sync
 			uint32_t rows[8], nrows = 0;

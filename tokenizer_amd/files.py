@@ -293,18 +293,6 @@ class ShardFile:
         import ctypes as C
         from . import annealing
         lib = annealing.load_library()
-        if not hasattr(lib.tokfiles_shard_read, "_bound"):
-            lib.tokfiles_shard_read.restype = C.c_int
-            lib.tokfiles_shard_read.argtypes = [C.POINTER(C.c_void_p), C.c_char_p, C.POINTER(C.c_int)]
-            lib.tokfiles_shard_docs.restype = C.c_uint64
-            lib.tokfiles_shard_docs.argtypes = [C.c_void_p]
-            lib.tokfiles_shard_bytes.restype = C.c_uint64
-            lib.tokfiles_shard_bytes.argtypes = [C.c_void_p, C.c_int]
-            lib.tokfiles_shard_copy.restype = C.c_int
-            lib.tokfiles_shard_copy.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
-            lib.tokfiles_shard_free.restype = None
-            lib.tokfiles_shard_free.argtypes = [C.c_void_p]
-            lib.tokfiles_shard_read._bound = True
         self.path_ = path
         h = C.c_void_p()
         valid = C.c_int(0)
