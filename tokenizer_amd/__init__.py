@@ -160,8 +160,12 @@ class Scorer:
         self._check(self._lib.tokscore_set_corpus_device(self._h, d_bytes_ptr, d_off_ptr, n_docs, total_bytes))
 
     # scoring -- main.cpp:38-43 accumulation + histogram of the ids Tokenize emits
-    def score(self, incremental: bool = False):
-        counts = np.zeros(self.V + 3, dtype=np.uint64)
+    def score(self, incremental: bool = False, out: np.ndarray = None):
+        """-> (counts[V+3], total_tokens, total_bytes); `out` (uint64[V+3]) is filled and returned
+        when given, so that a loop of moves allocates nothing."""
+        counts = np.zeros(self.V + 3, dtype=np.uint64) if out is None else out
+        if counts.dtype != np.uint64 or counts.size != self.V + 3 or not counts.flags.c_contiguous:
+            raise ValueError("out must be a contiguous uint64 array of V + 3 entries")
         tt = C.c_uint64()
         tb = C.c_uint64()
         fn = self._lib.tokscore_score_incremental if incremental else self._lib.tokscore_score

@@ -43,12 +43,13 @@ def run(tokens, corpus, off, moves, seed, paired=False, verify=0):
     s.score(incremental=True)
     s.drain_timings()
     chunks, wall = [], []
+    buf = np.zeros(len(tokens) + 3, dtype=np.uint64)
     t0 = time.perf_counter()
     for i in picks:
         t1 = time.perf_counter()
         enabled[i] = not enabled[i]
         s.toggle(int(i), bool(enabled[i]))
-        out = s.score(incremental=True)
+        out = s.score(incremental=True, out=buf)
         wall.append(time.perf_counter() - t1)
         chunks.append(s.info().rescored_chunks)
         if len(wall) <= verify:
