@@ -3,7 +3,7 @@
 (oracle/_ref/ref_harness `anneal`: GetTokens -> TokenGenerator -> Generate, hardware_concurrency
 workers, batch = 30 as the harness passes it) on the corpus tools/bench_anneal.py uses, so the two
 moves/s figures sit side by side.  Build container only (needs oracle/_ref).
-Usage: python tests/perf_anneal_vs_reference.py [mb] [passes]"""
+Usage: python tests/perf_anneal_vs_reference.py [mb] [passes] [batch]"""
 import json
 import os
 import subprocess
@@ -21,7 +21,7 @@ HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
 def main():
     mb = float(sys.argv[1]) if len(sys.argv) > 1 else 2.0
     passes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-    batch = os.cpu_count() or 1  # the reference's default batch_size (TokenGenerator.h:49)
+    batch = int(sys.argv[3]) if len(sys.argv) > 3 else (os.cpu_count() or 1)  # default: the reference's (TokenGenerator.h:49)
     corpus, off = synth.wiki_like(int(mb * 1e6), seed=20201120)
     b = corpus.tobytes()
     texts = [b[int(off[i]):int(off[i + 1])].decode("utf-8") for i in range(len(off) - 1)]
