@@ -12,9 +12,12 @@ SRC = [os.path.join(HERE, "native", "san_driver.cpp")] + [
     os.path.join(ROOT, "tokenizer_amd", "csrc", f) for f in ("candidates.cpp", "annealer.cpp", "shard_reader.cpp")]
 
 
-def _build_and_run(tmp_path, flags, threads, env=None):
+TRIE_SRC = [os.path.join(HERE, "native", "san_trie.cpp"), os.path.join(ROOT, "tokenizer_amd", "csrc", "trie.cpp")]
+
+
+def _build_and_run(tmp_path, flags, threads, env=None, src=None):
     exe = str(tmp_path / "san_driver")
-    subprocess.run(["g++", "-O1", "-g", "-std=c++20", "-pthread", "-fno-omit-frame-pointer"] + flags + ["-o", exe] + SRC,
+    subprocess.run(["g++", "-O1", "-g", "-std=c++20", "-pthread", "-fno-omit-frame-pointer"] + flags + ["-o", exe] + (src or SRC),
                    check=True)
     e = dict(os.environ)
     e.update(env or {})
@@ -27,6 +30,13 @@ def _build_and_run(tmp_path, flags, threads, env=None):
 def test_host_libraries_under_asan_ubsan(tmp_path):
     _build_and_run(tmp_path, ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], 1,
                    {"ASAN_OPTIONS": "detect_leaks=1"})
+
+
+def test_trie_builder_under_asan_ubsan(tmp_path):
+    # the host side of libtokscore.so: build, hot-first packing, toggles; answers checked against a
+    # plain longest match over the token list (duplicates: first id, SolutionFile.cpp:56)
+    _build_and_run(tmp_path, ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], 1,
+                   {"ASAN_OPTIONS": "detect_leaks=1"}, src=TRIE_SRC)
 
 
 def test_multi_worker_annealer_under_tsan(tmp_path):
