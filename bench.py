@@ -88,6 +88,44 @@ def measured_traffic(workload_bytes):
     return None, None
 
 
+def moves_per_sec(scorer, tokens, corpus, off):
+    """BASELINE.json's second figure, outside the timed region: (ii) toggle one
+    token + incremental re-score on the resident shard, against a full re-score per move; (i) the
+    host annealer's own loop (libtokanneal.so) on the candidates of a 1 MB slice."""
+    import os
+    from tokenizer_amd import annealing
+    rng = np.random.default_rng(5)
+    multi = [i for i, t in enumerate(tokens) if len(t.decode("utf-8", "ignore")) > 1]
+    picks = rng.choice(multi, size=120)
+    buf = np.zeros(len(tokens) + 3, dtype=np.uint64)
+    scorer.score(out=buf)
+    on = np.ones(len(tokens), dtype=bool)
+
+    def run(incremental, which):
+        t0 = time.perf_counter()
+        for i in which:
+            on[i] = not on[i]
+            scorer.toggle(int(i), bool(on[i]))
+            scorer.score(incremental=incremental, out=buf)
+        return len(which) / (time.perf_counter() - t0)
+
+    run(True, picks[:2])  # builds the occurrence index
+    inc = run(True, picks[2:])
+    full = run(False, picks[2:42])
+    docs = int(np.searchsorted(off, 1_000_000))
+    cands = annealing.GetTokens(corpus[:int(off[docs])], off[:docs + 1], 10)
+    n_cand = len(cands)
+    threads = min(16, os.cpu_count() or 1)
+    gen = annealing.TokenGenerator(cands, 30000, max(threads, 16))
+    t0 = time.perf_counter()
+    st = gen.Generate(0, threads=threads, seed=5)[-1]
+    host = st.gen_cnt / (time.perf_counter() - t0)
+    gen.close()
+    return {"gpu_toggle_incremental_rescore": inc, "gpu_toggle_full_rescore": full,
+            "host_dag_loop": host, "host_threads": threads, "host_candidates": n_cand,
+            "note": "moves/s; GPU: this shard and vocabulary, result on the host after every move"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +243,7 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             rec["cpu_baseline"] = cpu_baseline(corpus, off, tokens)
+            rec["annealing_moves_per_s"] = moves_per_sec(scorer, tokens, corpus, off)
         print(json.dumps(rec))
     scorer.close()
     if world > 1:
