@@ -361,6 +361,25 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	             : "v24", "v25", "v26", "v27", "s38", "s39", "s40", "s41", "s42", "s43", "vcc",    \
 	               "scc", "memory")
 
+// Per-wave time breakdown for tuning (make -C tokenizer_amd/csrc prof; tools/_prof/run_prof.py):
+// cycles per phase, chunks taken and finish time of every wave, left in g_prof.  Compiled out
+// of the product library.
+#ifdef TOK_PROFILE
+__device__ unsigned long long g_prof[4096 * 8];
+#define PROF_NOW() ((unsigned long long)__builtin_readcyclecounter())
+#define PROF_ADD(k, since)                          \
+	do {                                            \
+		const unsigned long long n_ = PROF_NOW();   \
+		prof_acc[k] += n_ - (since);                \
+		(since) = n_;                               \
+	} while (0)
+#else
+#define PROF_NOW() 0ull
+#define PROF_ADD(k, since) \
+	do {                   \
+	} while (0)
+#endif
+
 template <bool WIDE>
 __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C, ChunkState S, StreamDev Qd,
                                                          const uint64_t *chunk_first_doc, uint32_t seg_bytes,
@@ -405,6 +424,10 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	W.root_base = T.root_base;
 	W.unknown_id = T.unknown_id;
 
+	unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long prof_t = PROF_NOW();
+	const unsigned long long prof_start = prof_t;
+	(void)prof_acc, (void)prof_t, (void)prof_start;
 	const uint32_t queue = blockIdx.x % kWorkQueues;
 	const uint32_t min_seg = 4 * (((max_len + 4 + 3) / 4) | 1u); // shortest legal lane segment
 	constexpr int kMaxVec = 7; // register prefetch depth: up to 7 x 16 B per lane
@@ -419,6 +442,8 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 		j = __builtin_amdgcn_readfirstlane(j) * kWorkQueues + queue;
 		if (j >= S.nchunks) break;
 		if (chunk_sel && !((chunk_sel[j >> 5] >> (j & 31)) & 1u)) continue; // incremental re-score: only the selected chunks
+		PROF_ADD(0, prof_t); // queue
+		prof_acc[7]++;
 		const uint64_t begin = S.begin[j];
 		const uint64_t end = S.begin[j + 1];
 		uint64_t di = chunk_first_doc[j]; // index of the first document offset >= begin
@@ -520,6 +545,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			}
 			wave_sync();
 
+			PROF_ADD(1, prof_t); // tile load + bitmap
 			// ---- phase 1: speculative chain per lane segment ----
 			const uint32_t off0 = (uint32_t)(begin > a0 ? begin - a0 : 0); // only the chunk's first tile
 			const uint64_t rem = end - a0;
@@ -566,11 +592,13 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				if constexpr (WIDE) TOK_ASM_PHASE1("ds_write_b32", "256", "2", "448");
 				else TOK_ASM_PHASE1("ds_write_b16", "128", "1", "448");
 				(void)stall;
+				PROF_ADD(2, prof_t); // phase 1 loop
 				act = act_out;
 				log.cur = cur_out;
 				log.flush_if_full(Qd, lane);
 				if (has_bounds && ((act >> lane) & 1ull) && wk.lend > wk.cp && wk.cp >= lim_a)
 					lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
+				PROF_ADD(3, prof_t); // log flush, limit refresh
 			}
 			const unsigned long long mask = ((unsigned long long)mask_hi << 32) | mask_lo;
 			const uint32_t bound = mask ? seg_a + (63u - (uint32_t)__builtin_clzll(mask)) : first_a;
@@ -605,11 +633,13 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 						if constexpr (WIDE) TOK_ASM_REPAIR("ds_write_b32", "256", "2", "448");
 						else TOK_ASM_REPAIR("ds_write_b16", "128", "1", "448");
 						(void)stall;
+						PROF_ADD(4, prof_t); // repair loop
 						act = act_out;
 						log.cur = cur_out;
 						log.flush_if_full(Qd, lane);
 						if (has_bounds && ((act >> lane) & 1ull) && wk.lend > wk.cp && wk.cp >= lim_a)
 							lim_a = tile_a + find_limit(bitmap, wk.cp - tile_a, stop);
+						PROF_ADD(3, prof_t);
 					}
 					merged = (merged_m >> lane) & 1ull;
 					pa = wk.cp;
@@ -652,6 +682,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 				}
 			}
 
+			PROF_ADD(5, prof_t); // rest of phase 2: take-back, dual walk, round control
 			// ---- carry into the next tile / chunk exit ----
 			const unsigned long long ne = __ballot(nonempty);
 			const uint32_t last = 63u - (uint32_t)__builtin_clzll(ne); // lane 0 is always non-empty
@@ -665,6 +696,15 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 		}
 	}
 	log.finish(Qd, lane);
+#ifdef TOK_PROFILE
+	PROF_ADD(0, prof_t);
+	if (lane == 0) {
+		unsigned long long *row = g_prof + (size_t)((blockIdx.x * 16 + wave) % 4096) * 8;
+		for (int k = 0; k < 6; k++) row[k] = prof_acc[k];
+		row[6] = prof_t - prof_start;
+		row[7] = prof_acc[7];
+	}
+#endif
 }
 
 // ---- token stream -> counts ------------------------------------------------------------
@@ -866,3 +906,9 @@ void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, 
 }
 
 } // namespace tokscore
+
+#ifdef TOK_PROFILE
+extern "C" int tokscore_debug_prof(unsigned long long *out, size_t n) {
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(tokscore::g_prof), n * sizeof(unsigned long long));
+}
+#endif
