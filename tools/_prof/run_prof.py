@@ -24,3 +24,17 @@ for k, n in enumerate(names):
     v = rows[:, k].astype(float)
     print("%-20s mean %10.0f  (%5.1f %% of mean total)  min %10.0f max %10.0f" % (n, v.mean(), 100 * v.mean() / tot.mean(), v.min(), v.max()))
 print("finish time: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f" % tuple(np.percentile(tot, [0, 10, 50, 90, 100])))
+# per workgroup: do whole workgroups run slow (placement) or single waves?
+allrows = buf.reshape(4096, 8)
+wg_chunks = []
+for b in range(256):
+    r = allrows[b * 16:(b + 1) * 16]
+    r = r[r[:, 6] > 0]
+    if len(r):
+        wg_chunks.append((r[:, 7].sum(), r[:, 6].max(), b))
+wg_chunks.sort()
+print("chunks per workgroup: min %d p10 %d median %d p90 %d max %d" % tuple(np.percentile([c[0] for c in wg_chunks], [0, 10, 50, 90, 100])))
+print("slowest workgroups (chunks, finish, id):", wg_chunks[:8])
+print("fastest workgroups:", wg_chunks[-8:])
+fin = np.array([c[1] for c in wg_chunks], dtype=float)
+print("workgroup finish: min %.0f median %.0f max %.0f" % (fin.min(), np.median(fin), fin.max()))
