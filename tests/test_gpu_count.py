@@ -75,3 +75,33 @@ def test_edge_cases():
         exp = voc.count_occurrences(corpus, off, 3)
         got = _gpu_counts(names, (corpus, off), 3)
         assert np.array_equal(got[0], exp[0]) and got[1] == exp[1], docs
+
+
+def test_many_tiny_documents():
+    # hundreds of document starts inside one 1 KiB tile: the bitmap is built in several rounds
+    rng = np.random.default_rng(11)
+    alphabet = [b"a", b"b", b"ab", "é".encode(), "語".encode(), b" "]
+    docs = []
+    for _ in range(60_000):
+        n = int(rng.integers(0, 4))
+        docs.append(b"".join(alphabet[int(i)] for i in rng.integers(0, len(alphabet), n)))
+    names = [b"a", b"b", b"ab", b"ba", b"aab", "é".encode(), "語".encode(), "é語".encode(), b" a", b"a b", b"abab"]
+    voc = O.OracleVocab(*synth.pack_vocab(names))
+    corpus, off = synth.pack_docs(docs)
+    exp = voc.count_occurrences(corpus, off, 4)
+    got = _gpu_counts(names, (corpus, off), 4)
+    assert np.array_equal(got[0], exp[0]) and got[1] == exp[1]
+
+
+def test_long_tokens_take_the_unprefetched_tile_path():
+    # a 1,500-byte candidate: the staged halo no longer fits the register prefetch
+    rng = np.random.default_rng(12)
+    base = bytes(rng.integers(97, 123, 1500).astype(np.uint8))
+    docs = [base + b" tail", b"x" + base, base[:700], b"short", base + base]
+    names = [base, base[:700], base[:3], b"x" + base[:10], b"tail"]
+    voc = O.OracleVocab(*synth.pack_vocab(names))
+    corpus, off = synth.pack_docs(docs)
+    exp = voc.count_occurrences(corpus, off, 1600)
+    got = _gpu_counts(names, (corpus, off), 1600)
+    assert np.array_equal(got[0], exp[0]) and got[1] == exp[1]
+    assert got[0][2] == 4  # the long one: documents 0 and 1, twice in document 4

@@ -84,10 +84,15 @@ struct CountPlan {
 };
 bool plan_count(const TrieDev &T, uint64_t max_len_bytes, uint32_t max_cp, uint32_t n_ids, CountPlan *plan);
 uint32_t count_tiles(uint64_t total_bytes);
+uint32_t count_blocks(uint64_t total_bytes, uint32_t num_cus);
+size_t count_head_words(const CountPlan &plan);
 // One pass per id range; every pass writes its id columns of all `blocks` slab rows
 // (n_ids + 1 columns; the last one = code-point positions, written by the first pass).
-void launch_count_all(const TrieDev &T, const CorpusDev &C, const CountPlan &plan, uint32_t max_cp, uint32_t n_ids,
-                      uint32_t blocks, uint32_t *tile_counters, uint32_t *slab, hipStream_t stream);
+// Scratch: heads[count_head_words(plan)] (queue heads, set here), tile_first[count_tiles()].
+// walks = trie walks a lane keeps in flight (2 or 4).
+hipError_t launch_count_all(const TrieDev &T, const CorpusDev &C, const CountPlan &plan, uint32_t max_cp, uint32_t n_ids,
+                            uint32_t blocks, uint32_t walks, uint32_t *heads, uint64_t *tile_first, uint32_t *slab,
+                            hipStream_t stream);
 
 // kernels_extract.hip (row f3): the candidate set of the resident corpus, arrays in device memory
 constexpr uint32_t kExtractMaxCp = 32;

@@ -861,23 +861,30 @@ int tokscore_count_occurrences(tokscore_ctx *c, uint32_t max_cp, uint64_t *count
 	if (!plan_count(T, c->packed.max_len, max_cp, n_ids, &plan))
 		return fail(c, TOKSCORE_E_CAPACITY, "tokens too long for the counting kernel's LDS tile");
 	const uint32_t tiles = count_tiles(c->total);
-	const uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>((uint32_t)c->num_cus, tiles));
-	// a slab cell is an int32 partial of one workgroup
-	if (c->total / blocks >= 0x7FFFFFFFull) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one counting launch");
+	const uint32_t blocks = count_blocks(c->total, (uint32_t)c->num_cus);
+	// a slab cell is an int32 partial of one workgroup; tiles are handed out dynamically, so
+	// leave room for a workgroup that gets four times its share
+	if (c->total / blocks >= 0x7FFFFFFFull / 4) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one counting launch");
+	static const uint32_t walks = [] {
+		const char *e = getenv("TOKSCORE_COUNT_WALKS");
+		return e && atoi(e) == 4 ? 4u : 2u; // 2: 1.82 ms, 4: 1.90 ms on the 100 MB bench shard
+	}();
 	uint32_t *d_slab = nullptr, *d_tiles = nullptr;
+	uint64_t *d_first = nullptr;
 	HIP_TRY(c, hipMalloc((void **)&d_slab, (size_t)blocks * (n_ids + 1) * sizeof(uint32_t)));
-	hipError_t e = hipMalloc((void **)&d_tiles, plan.passes * sizeof(uint32_t));
+	hipError_t e = hipMalloc((void **)&d_tiles, count_head_words(plan) * sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMalloc((void **)&d_first, std::max<size_t>(1, tiles) * sizeof(uint64_t));
 	std::vector<uint64_t> host(c->V + 5);
 	do {
 		if (e != hipSuccess) break;
-		if ((e = hipMemsetAsync(d_tiles, 0, plan.passes * sizeof(uint32_t), c->stream)) != hipSuccess) break;
 		if ((e = hipMemsetAsync(c->d_out, 0, (c->V + 5) * sizeof(unsigned long long), c->stream)) != hipSuccess) break;
-		launch_count_all(T, C, plan, max_cp, n_ids, blocks, d_tiles, d_slab, c->stream);
+		if ((e = launch_count_all(T, C, plan, max_cp, n_ids, blocks, walks, d_tiles, d_first, d_slab, c->stream)) != hipSuccess) break;
 		launch_slab_reduce(d_slab, blocks, n_ids + 1, c->d_out, c->stream);
 		if ((e = hipGetLastError()) != hipSuccess) break;
 		if ((e = hipMemcpyAsync(host.data(), c->d_out, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) break;
 		e = hipStreamSynchronize(c->stream);
 	} while (0);
+	if (d_first) (void)hipFree(d_first);
 	(void)hipFree(d_slab);
 	if (d_tiles) (void)hipFree(d_tiles);
 	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("count_occurrences: ") + hipGetErrorString(e));
