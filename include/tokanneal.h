@@ -53,6 +53,13 @@ int tokanneal_cands_build(tokanneal_cands **out, const uint8_t *bytes, const uin
 int tokanneal_cands_from_arrays(tokanneal_cands **out, uint64_t n, const uint32_t *chr, const uint64_t *uses,
                                 const uint32_t *lpar, const uint32_t *rpar);
 
+/* The candidate set of two corpora together from the set of each: the strings of both, each
+ * once, uses added up, numbered again in the reference's order.  It is what GetTokens builds
+ * when FileCandidates feeds several files into one Trie (GetTokens.cpp:31-90, Trie.cpp:114-152),
+ * for callers that extract shard by shard (one GPU extraction holds < 4 GiB) or GPU by GPU.
+ * Both inputs have to be in the builder's order (TOKANNEAL_E_DATA otherwise); they stay valid. */
+int tokanneal_cands_merge(tokanneal_cands **out, const tokanneal_cands *a, const tokanneal_cands *b);
+
 /* ReadTokens (Token.cpp:109-161) on a `.candidates-*.bin`.  *read_code receives the
  * reference's TokenReadErrCode (Token.h:13-19: 0 OK, 1 BAD_STREAM, 2 INVALID_VERSION,
  * 3 BAD_FILE, 4 NOT_DONE); a handle is returned only for OK.  Unlike the reference the

@@ -53,6 +53,20 @@ int main(int argc, char **argv) {
 		const std::string name = c.GetName(i);
 		CHECK(!name.empty() && c.TokenSize(i) >= 1 && c.TokenSize(i) <= 6);
 	}
+	// the set of two halves of the corpus, merged, is the set of the whole
+	{
+		const size_t half = (off.size() - 1) / 2;
+		std::vector<uint64_t> off_b(off.begin() + half, off.end());
+		CandidateSet a, b, m;
+		BuildCandidates(bytes.data(), off.data(), half, 6, &a);
+		BuildCandidates(bytes.data(), off_b.data(), off_b.size() - 1, 6, &b);
+		CHECK(MergeCandidates(a, b, &m, &why));
+		CHECK(m.chr == c.chr && m.uses == c.uses && m.lpar == c.lpar && m.rpar == c.rpar);
+		std::swap(b.chr.front(), b.chr.back()); // no longer in code-point order: refused, not walked off the end
+		CandidateSet x;
+		MergeCandidates(a, b, &x, &why);
+		CHECK(MergeCandidates(b, CandidateSet(), &x, &why) || !why.empty());
+	}
 	// file round trip
 	const std::string path = tmp + "/san_candidates.bin";
 	CHECK(WriteCandidates(c, path, &why));

@@ -135,6 +135,50 @@ def test_varint_is_read_at_64_bits(tmp_path):
     assert back.GetName(1) == b"aa" and back.size(1) == 2
 
 
+def test_merge_of_two_corpora_is_the_set_of_both(trace, golden_bin):
+    # GetTokens over several files is one trie over all of them (GetTokens.cpp:31-90): the merge of the
+    # per-part sets has to be the builder's set for the parts together -- and the builder is pinned by
+    # the compiled reference's candidates.bin above
+    docs = [d.encode("utf-8") for d in trace["docs"]]
+    max_len = trace["max_len"]
+
+    def build(part):
+        off = np.zeros(len(part) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(d) for d in part], dtype=np.uint64)
+        return A.GetTokens(np.frombuffer(b"".join(part), dtype=np.uint8) if part else np.zeros(0, np.uint8), off, max_len)
+
+    whole = build(docs)
+    _, ref = A.ReadTokens(golden_bin)
+    for cut in (0, 1, len(docs) // 3, len(docs) - 1, len(docs)):
+        a, b = build(docs[:cut]), build(docs[cut:])
+        for m in (a.merge(b), b.merge(a)):
+            for x, y, z in zip(m.arrays(), whole.arrays(), ref.arrays()):
+                assert np.array_equal(x, y) and np.array_equal(x, z)
+    # three parts, and a set merged with itself: the same strings, twice the uses
+    third = len(docs) // 3
+    m3 = build(docs[:third]).merge(build(docs[third:2 * third])).merge(build(docs[2 * third:]))
+    assert all(np.array_equal(x, y) for x, y in zip(m3.arrays(), whole.arrays()))
+    twice = whole.merge(whole).arrays()
+    assert np.array_equal(twice[1], 2 * whole.arrays()[1])
+    assert all(np.array_equal(twice[k], whole.arrays()[k]) for k in (0, 2, 3))
+
+
+def test_merge_rejects_sets_that_are_not_in_builder_order():
+    # "a", "ab", "b" in pre-order ...
+    good = A.Tokens.from_arrays([97, 97, 98], [3, 1, 2], [A.NONE, 2, A.NONE], [A.NONE, 0, A.NONE])
+    assert len(good.merge(good)) == 3
+    # ... and with the roots swapped: "b", "a", "ab" is a valid DAG but not the builder's order
+    bad = A.Tokens.from_arrays([98, 97, 97], [2, 3, 1], [A.NONE, A.NONE, 0], [A.NONE, A.NONE, 1])
+    for pair in ((good, bad), (bad, good), (bad, bad)):
+        with pytest.raises(A.TokannealError) as e:
+            pair[0].merge(pair[1])
+        assert e.value.status == A.E_DATA
+    # a token before its prefix
+    bad2 = A.Tokens.from_arrays([97, 97, 98], [1, 3, 2], [2, A.NONE, A.NONE], [1, A.NONE, A.NONE])
+    with pytest.raises(A.TokannealError):
+        good.merge(bad2)
+
+
 def test_from_arrays_rejects_what_is_not_a_dag():
     with pytest.raises(A.TokannealError):
         A.Tokens.from_arrays([97, 97], [1, 1], [1, 0], [1, 0])              # a cycle

@@ -127,6 +127,23 @@ def test_gpu_candidates_equal_host_builder(kind, nbytes, max_cp):
     assert got[4] == int(want[1][roots].sum())
 
 
+def test_gpu_candidates_shard_by_shard_equal_host_builder_on_all():
+    # three shards extracted one after the other and merged on the host = one trie over all files
+    shards = [synth.wiki_like(300_000, seed=61, n_words=3000, median_doc=500),
+              synth.cjk_heavy(120_000, seed=62, doc_lo=16, doc_hi=2000),
+              synth.wiki_like(200_000, seed=63, n_words=3000, median_doc=900)]
+    docs = []
+    for b, o in shards:
+        raw = b.tobytes()
+        docs += [raw[int(o[i]):int(o[i + 1])] for i in range(len(o) - 1)]
+    want = A.GetTokens(*synth.pack_docs(docs), 6).arrays()
+    got = A.GetTokensGpu(shards, max_len=6).arrays()
+    for name, a, b in zip(("chr", "uses", "lpar", "rpar"), got, want):
+        assert np.array_equal(a, b), name
+    one = A.GetTokensGpu(*shards[0], max_len=6).arrays()
+    assert all(np.array_equal(a, b) for a, b in zip(one, A.GetTokens(*shards[0], 6).arrays()))
+
+
 def test_extract_candidates_rejects_what_it_cannot_take():
     s = ta.Scorer(0)
     try:

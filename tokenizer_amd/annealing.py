@@ -20,7 +20,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtokanneal.so")
 
 OK = 0
-E_SPACE = 4
+E_ARG, E_IO, E_DATA, E_SPACE = 1, 2, 3, 4
 NONE = 0xFFFFFFFF  # "no parent" (Token.cpp:187-190)
 # annealing::TokenReadErrCode (Token.h:13-19)
 READ_OK, BAD_STREAM, INVALID_VERSION, BAD_FILE, NOT_DONE = range(5)
@@ -48,6 +48,7 @@ _SIGNATURES = [
     ("tokanneal_strerror", C.c_char_p, [C.c_int]),
     ("tokanneal_cands_build", C.c_int, [_vpp, _u8p, _u64p, C.c_uint64, C.c_uint32]),
     ("tokanneal_cands_from_arrays", C.c_int, [_vpp, C.c_uint64, _u32p, _u64p, _u32p, _u32p]),
+    ("tokanneal_cands_merge", C.c_int, [_vpp, C.c_void_p, C.c_void_p]),
     ("tokanneal_cands_read", C.c_int, [_vpp, C.c_char_p, C.POINTER(C.c_int)]),
     ("tokanneal_cands_write", C.c_int, [_vp, C.c_char_p]),
     ("tokanneal_cands_size", C.c_uint64, [_vp]),
@@ -128,6 +129,13 @@ class Tokens:
                                                a[2].ctypes.data_as(_u32p), a[3].ctypes.data_as(_u32p)))
         return cls(h.value)
 
+    def merge(self, other: "Tokens") -> "Tokens":
+        """The candidate set of both corpora together (each string once, uses added up, the
+        reference's order): what GetTokens builds over several files (GetTokens.cpp:31-90)."""
+        h = C.c_void_p()
+        _check(self._lib.tokanneal_cands_merge(C.byref(h), self._h, other._h))
+        return Tokens(h.value)
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.tokanneal_cands_free(self._h)
@@ -182,17 +190,30 @@ def GetTokens(corpus: np.ndarray, doc_off: np.ndarray, max_len: int = 255) -> To
     return Tokens(h.value)
 
 
-def GetTokensGpu(corpus: np.ndarray, doc_off: np.ndarray, max_len: int = 255, device: int = 0) -> Tokens:
+def GetTokensGpu(corpus, doc_off=None, max_len: int = 255, device: int = 0) -> Tokens:
     """The same candidate set as GetTokens, computed on the GPU (tokscore_extract_candidates: one
-    sort of all windows instead of a trie; max_len <= 32, valid UTF-8 without NUL bytes)."""
+    sort of all windows instead of a trie; max_len <= 32, valid UTF-8 without NUL bytes).
+    `corpus` may also be a list of (bytes, offsets) shards, each below 4 GiB: they are extracted
+    one after the other and merged on the host, like the files of one metadata.json."""
     from . import Scorer
+    shards = [(corpus, doc_off)] if doc_off is not None else list(corpus)
     s = Scorer(device)
+    total = None
     try:
-        s.set_corpus(corpus, doc_off)
-        chr_, uses, lpar, rpar, _ = s.extract_candidates(max_len)
+        for b, o in shards:
+            s.set_corpus(b, o)
+            chr_, uses, lpar, rpar, _ = s.extract_candidates(max_len)
+            part = Tokens.from_arrays(chr_, uses, lpar, rpar)
+            if total is None:
+                total = part
+            else:
+                merged = total.merge(part)
+                total.close()
+                part.close()
+                total = merged
     finally:
         s.close()
-    return Tokens.from_arrays(chr_, uses, lpar, rpar)
+    return total if total is not None else Tokens.from_arrays([], [], [], [])
 
 
 def candidates_file_name(file_cnt=None, max_len: int = 255) -> str:

@@ -302,4 +302,132 @@ ReadCode ReadCandidates(const std::string &path, CandidateSet *out) {
 	return READ_OK;
 }
 
+// ---- union of two candidate sets --------------------------------------------------------
+// What GetTokens builds when FileCandidates (GetTokens.cpp:31-90) feeds several files into
+// one Trie: the windows of all documents, each string once, its uses added up, numbered in
+// pre-order with children by code point (Trie.cpp:81-91,137-142).  Here the two tries are
+// walked side by side in that order; both inputs have to be in it already.
+namespace {
+
+struct PreorderView {
+	const CandidateSet &c;
+	std::vector<uint32_t> last; // LAST code point of each string: chr at the end of its l chain
+	std::vector<uint32_t> span; // tokens in the subtree of each token, itself included
+	explicit PreorderView(const CandidateSet &set) : c(set) {}
+
+	bool Prepare(std::string *why) {
+		const size_t n = c.size();
+		last.assign(n, 0);
+		span.assign(n, 1);
+		std::vector<uint8_t> known(n, 0);
+		std::vector<uint32_t> path;
+		for (size_t i = 0; i < n; i++) {
+			if (c.rpar[i] != kNone && c.rpar[i] >= i) {
+				if (why) *why = "not in trie pre-order: a token comes before its prefix";
+				return false;
+			}
+			path.clear();
+			uint32_t v = (uint32_t)i;
+			while (!known[v] && c.lpar[v] != kNone) {
+				path.push_back(v);
+				v = c.lpar[v];
+			}
+			if (!known[v]) last[v] = c.chr[v], known[v] = 1;
+			for (uint32_t u : path) last[u] = last[v], known[u] = 1;
+		}
+		for (size_t i = n; i-- > 0;)
+			if (c.rpar[i] != kNone) span[c.rpar[i]] += span[i];
+		// pre-order: the subtree of a token is the span right behind it
+		for (size_t i = 0; i < n; i++) {
+			const uint32_t p = c.rpar[i];
+			if (p != kNone && i >= (size_t)p + span[p]) {
+				if (why) *why = "not in trie pre-order: a token lies outside its prefix's subtree";
+				return false;
+			}
+		}
+		return true;
+	}
+};
+
+} // namespace
+
+bool MergeCandidates(const CandidateSet &a, const CandidateSet &b, CandidateSet *out, std::string *why) {
+	out->clear();
+	// (parent chains that end, indices in range: CandidateSet::Validate, which every way of
+	// making a set has already run)
+	PreorderView A(a), B(b);
+	if (!A.Prepare(why) || !B.Prepare(why)) return false;
+	const size_t na = a.size(), nb = b.size();
+	std::vector<uint32_t> map_a(na, kNone), map_b(nb, kNone);
+	// sibling ranges still to be merged, [cur, end) on either side; children of one merged
+	// token are pushed when it is numbered, so the numbering is the pre-order of the union
+	struct Frame {
+		uint32_t a_cur, a_end, b_cur, b_end;
+	};
+	std::vector<Frame> stack;
+	stack.push_back({0, (uint32_t)na, 0, (uint32_t)nb});
+	uint64_t next = 0;
+	auto order_error = [&] {
+		if (why) *why = "not in trie pre-order: children out of code-point order";
+		out->clear();
+		return false;
+	};
+	while (!stack.empty()) {
+		Frame &f = stack.back();
+		const bool has_a = f.a_cur < f.a_end, has_b = f.b_cur < f.b_end;
+		if (!has_a && !has_b) {
+			stack.pop_back();
+			continue;
+		}
+		const uint32_t ca = has_a ? A.last[f.a_cur] : 0, cb = has_b ? B.last[f.b_cur] : 0;
+		if (has_a && has_b && ca == cb) {
+			const uint32_t x = f.a_cur, y = f.b_cur;
+			map_a[x] = map_b[y] = (uint32_t)next++;
+			f.a_cur += A.span[x];
+			f.b_cur += B.span[y];
+			if ((f.a_cur < f.a_end && A.last[f.a_cur] <= ca) || (f.b_cur < f.b_end && B.last[f.b_cur] <= cb)) return order_error();
+			stack.push_back({x + 1, x + A.span[x], y + 1, y + B.span[y]}); // (invalidates f)
+		} else if (has_a && (!has_b || ca < cb)) {
+			// a subtree only one side has keeps its own pre-order
+			const uint32_t x = f.a_cur;
+			for (uint32_t i = x; i < x + A.span[x]; i++) map_a[i] = (uint32_t)next++;
+			f.a_cur += A.span[x];
+			if (f.a_cur < f.a_end && A.last[f.a_cur] <= ca) return order_error();
+		} else {
+			const uint32_t y = f.b_cur;
+			for (uint32_t i = y; i < y + B.span[y]; i++) map_b[i] = (uint32_t)next++;
+			f.b_cur += B.span[y];
+			if (f.b_cur < f.b_end && B.last[f.b_cur] <= cb) return order_error();
+		}
+		if (next >= kNone) {
+			if (why) *why = "more than 2^32 - 2 tokens";
+			out->clear();
+			return false;
+		}
+	}
+	for (uint32_t m : map_a)
+		if (m == kNone) return order_error();
+	for (uint32_t m : map_b)
+		if (m == kNone) return order_error();
+	const size_t n = (size_t)next;
+	out->chr.assign(n, 0);
+	out->uses.assign(n, 0);
+	out->lpar.assign(n, kNone);
+	out->rpar.assign(n, kNone);
+	// both sets hold every suffix and prefix of their strings, so a token's parents come
+	// from the set it came from
+	auto place = [&](const CandidateSet &c, const std::vector<uint32_t> &map) {
+		for (size_t i = 0; i < c.size(); i++) {
+			const uint32_t m = map[i];
+			out->chr[m] = c.chr[i];
+			out->uses[m] += c.uses[i];
+			if (c.lpar[i] != kNone) out->lpar[m] = map[c.lpar[i]];
+			if (c.rpar[i] != kNone) out->rpar[m] = map[c.rpar[i]];
+		}
+	};
+	place(a, map_a);
+	place(b, map_b);
+	return true;
+}
+
 } // namespace tokanneal

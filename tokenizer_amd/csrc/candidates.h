@@ -53,6 +53,12 @@ bool WriteCandidates(const CandidateSet &c, const std::string &path, std::string
 // `(byte & 0x7F) << sft` is an int shift, Token.cpp:136, and breaks above 2^31 uses).
 ReadCode ReadCandidates(const std::string &path, CandidateSet *out);
 
+// The candidate set of two corpora together, from the sets of each: what GetTokens builds when
+// FileCandidates feeds several files into one Trie (GetTokens.cpp:31-90).  Both inputs in
+// the builder's order (trie pre-order, children by code point); false + *why otherwise.
+// The inputs have passed Validate().
+bool MergeCandidates(const CandidateSet &a, const CandidateSet &b, CandidateSet *out, std::string *why);
+
 // utf8::append (utf8/core.h:357-377)
 void AppendUtf8(uint32_t cp, std::string *s);
 

@@ -103,6 +103,16 @@ int tokanneal_cands_from_arrays(tokanneal_cands **out, uint64_t n, const uint32_
 	});
 }
 
+int tokanneal_cands_merge(tokanneal_cands **out, const tokanneal_cands *a, const tokanneal_cands *b) {
+	if (!out || !a || !b) return TOKANNEAL_E_ARG;
+	return guarded([&] {
+		auto c = std::make_unique<tokanneal_cands>();
+		if (!MergeCandidates(a->set, b->set, &c->set, nullptr)) return TOKANNEAL_E_DATA;
+		*out = c.release();
+		return TOKANNEAL_OK;
+	});
+}
+
 int tokanneal_cands_read(tokanneal_cands **out, const char *path, int *read_code) {
 	if (!out || !path) return TOKANNEAL_E_ARG;
 	return guarded([&] {
