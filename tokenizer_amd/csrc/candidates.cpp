@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 namespace tokanneal {
 
@@ -356,7 +357,19 @@ bool MergeCandidates(const CandidateSet &a, const CandidateSet &b, CandidateSet 
 	// (parent chains that end, indices in range: CandidateSet::Validate, which every way of
 	// making a set has already run)
 	PreorderView A(a), B(b);
-	if (!A.Prepare(why) || !B.Prepare(why)) return false;
+	{
+		// the two views are independent and bound by memory latency: one thread each
+		bool ok_b = false;
+		std::string why_b;
+		std::thread tb([&] { ok_b = B.Prepare(&why_b); });
+		const bool ok_a = A.Prepare(why);
+		tb.join();
+		if (!ok_a) return false;
+		if (!ok_b) {
+			if (why) *why = why_b;
+			return false;
+		}
+	}
 	const size_t na = a.size(), nb = b.size();
 	std::vector<uint32_t> map_a(na, kNone), map_b(nb, kNone);
 	// sibling ranges still to be merged, [cur, end) on either side; children of one merged
@@ -416,14 +429,24 @@ bool MergeCandidates(const CandidateSet &a, const CandidateSet &b, CandidateSet 
 	out->rpar.assign(n, kNone);
 	// both sets hold every suffix and prefix of their strings, so a token's parents come
 	// from the set it came from
+	// (the tokens of one set land on different merged tokens, so its slices can go in parallel;
+	// the two sets share merged tokens and go one after the other)
 	auto place = [&](const CandidateSet &c, const std::vector<uint32_t> &map) {
-		for (size_t i = 0; i < c.size(); i++) {
-			const uint32_t m = map[i];
-			out->chr[m] = c.chr[i];
-			out->uses[m] += c.uses[i];
-			if (c.lpar[i] != kNone) out->lpar[m] = map[c.lpar[i]];
-			if (c.rpar[i] != kNone) out->rpar[m] = map[c.rpar[i]];
-		}
+		const size_t total = c.size();
+		const size_t workers = total < (1u << 20) ? 1 : std::min<size_t>(8, std::max(1u, std::thread::hardware_concurrency()));
+		auto slice = [&](size_t lo, size_t hi) {
+			for (size_t i = lo; i < hi; i++) {
+				const uint32_t m = map[i];
+				out->chr[m] = c.chr[i];
+				out->uses[m] += c.uses[i];
+				if (c.lpar[i] != kNone) out->lpar[m] = map[c.lpar[i]];
+				if (c.rpar[i] != kNone) out->rpar[m] = map[c.rpar[i]];
+			}
+		};
+		std::vector<std::thread> pool;
+		for (size_t w = 1; w < workers; w++) pool.emplace_back(slice, total * w / workers, total * (w + 1) / workers);
+		slice(0, total / workers);
+		for (std::thread &t : pool) t.join();
 	};
 	place(a, map_a);
 	place(b, map_b);
