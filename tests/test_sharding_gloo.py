@@ -12,6 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import oracle_ffi as O
+from tokenizer_amd import annealing as A
 from tokenizer_amd import shard, synth
 
 
@@ -74,3 +75,36 @@ def test_two_rank_gloo_allreduce_equals_single_evaluation():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert np.array_equal(got, expect)
+
+
+def _extract_worker(rank, world, port, corpus, off, max_cp, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c, o = shard.shard_corpus(corpus, off, rank, world)
+    # (the host builder stands in for the GPU extraction, which gives the same arrays: test_gpu_anneal.py)
+    merged = shard.merge_candidates_across_ranks(A.GetTokens(c, o, max_cp), dist)
+    assert (merged is not None) == (rank == 0)
+    if rank == 0:
+        q.put(merged.arrays())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 3])
+def test_candidates_merged_up_the_rank_tree_equal_one_extraction(world):
+    corpus, off = synth.wiki_like(400_000, seed=21, n_words=3000, median_doc=600)
+    expect = A.GetTokens(corpus, off, 6).arrays()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_extract_worker, args=(r, world, port, corpus, off, 6, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(got, expect):
+        assert np.array_equal(a, b)
