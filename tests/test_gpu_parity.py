@@ -122,6 +122,20 @@ def test_wide_vocabulary_uses_32bit_stream():
     assert np.array_equal(counts, exp[0])
 
 
+def test_deep_128k_vocabulary_on_random_utf8():
+    # SURVEY section 8 config 4 at test size: random UTF-8 over a 4k alphabet, V = 128k tokens of 2..10 code
+    # points cut from the corpus itself (deep trie, most of it outside LDS, four histogram id ranges)
+    corpus, off = synth.random_utf8(3_000_000, seed=355, doc_lo=4096, doc_hi=400_000)
+    tokens = synth.sample_vocab(corpus, 128_000)
+    assert len(tokens) > 128_000
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    exp = voc.score(corpus, off, threads=8)
+    for cfg in ({"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "generic"}):
+        (counts, tt, tb), info = _score_with(cfg, tokens, corpus, off)
+        assert (tt, tb) == exp[1:], cfg
+        assert np.array_equal(counts, exp[0]), cfg
+
+
 def test_empty_and_tiny_corpora():
     tokens = [b"a", b"b", b"ab"]
     for docs in ([], [b""], [b"", b"", b""], [b"a"], [b"", b"ab", b"", b"zab"]):

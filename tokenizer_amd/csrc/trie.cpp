@@ -164,40 +164,80 @@ bool VocabTrie::Pack(PackedTrie *out, std::string *err) {
 
 	std::vector<uint8_t> used(1024, 0);      // slot occupied
 	std::vector<uint8_t> base_used(1024, 0); // value already serves as some node's base
+	// next_free[s] = a slot >= s that is free, or leads to one (slots only ever go from free to
+	// used, so the links are compressed as they are followed): the search below visits free
+	// slots only, however dense the array has become
+	std::vector<uint32_t> next_free(1024);
+	for (uint32_t i = 0; i < 1024; i++) next_free[i] = i;
 	auto ensure = [&](uint64_t n) {
 		if (used.size() < n) {
-			const uint64_t m = std::max<uint64_t>(n, used.size() * 2);
+			const uint64_t old = used.size();
+			const uint64_t m = std::max<uint64_t>(n, old * 2);
 			used.resize(m, 0);
 			base_used.resize(m, 0);
+			next_free.resize(m);
+			for (uint64_t i = old; i < m; i++) next_free[i] = (uint32_t)i;
 		}
 	};
+	auto find_free = [&](uint64_t s) -> uint64_t {
+		ensure(s + 1);
+		uint64_t r = s;
+		while (next_free[r] != r) {
+			r = next_free[r];
+			ensure(r + 1);
+		}
+		while (next_free[s] != r) { // compress
+			const uint64_t t = next_free[s];
+			next_free[s] = (uint32_t)r;
+			s = t;
+		}
+		return r;
+	};
+	// A deep vocabulary (long tokens over a large alphabet) is mostly single-child nodes, and a
+	// hole whose 256 possible bases are all taken can never be filled: after this many free
+	// slots tried, the node takes the first fitting base above every base handed out so far.
+	constexpr uint32_t kMaxTries = 256;
 	node_slot_.assign(N, 0);
 	std::vector<uint32_t> node_base(N, 0);
 	used[0] = 1; // root
-	uint64_t first_free = 1;
-	uint64_t max_used = 0;
+	next_free[0] = 1;
+	uint64_t max_used = 0, max_base = 0;
 	for (uint32_t node : parents) {
 		const Edge *e = edges_.data() + first_child_[node];
 		const uint32_t nc = n_children_[node];
 		const uint32_t c0 = e[0].byte;
-		while (first_free < used.size() && used[first_free]) first_free++;
-		// smallest unused base b >= 1 with every slot b + c free
-		uint64_t b = first_free > c0 ? first_free - c0 : 1;
-		for (;;) {
+		// smallest unused base b >= 1 with every slot b + c free: candidates are the bases that
+		// put the first child on a free slot
+		uint64_t s = find_free(std::max<uint64_t>(1, (uint64_t)c0 + 1));
+		uint64_t b = 0;
+		for (uint32_t tries = 0;; tries++) {
+			b = s - c0;
 			ensure(b + 257);
 			bool ok = !base_used[b];
 			for (uint32_t k = 0; ok && k < nc; k++) ok = !used[b + e[k].byte];
 			if (ok) break;
-			b++;
-			// skip ahead to the next base whose first child slot is free
-			while (b + c0 < used.size() && used[b + c0]) b++;
+			if (tries >= kMaxTries) {
+				// no base above max_base is taken: the first one whose slots are free
+				for (b = max_base + 1;; b++) {
+					ensure(b + 257);
+					bool fits = true;
+					for (uint32_t k = 0; fits && k < nc; k++) fits = !used[b + e[k].byte];
+					if (fits) break;
+				}
+				break;
+			}
+			s = find_free(s + 1);
 		}
 		base_used[b] = 1;
+		max_base = std::max(max_base, b);
 		node_base[node] = (uint32_t)b;
 		for (uint32_t k = 0; k < nc; k++) {
-			used[b + e[k].byte] = 1;
-			node_slot_[e[k].child] = (uint32_t)(b + e[k].byte);
-			max_used = std::max<uint64_t>(max_used, b + e[k].byte);
+			const uint64_t slot = b + e[k].byte;
+			used[slot] = 1;
+			ensure(slot + 2);
+			next_free[slot] = (uint32_t)(slot + 1);
+			node_slot_[e[k].child] = (uint32_t)slot;
+			max_used = std::max<uint64_t>(max_used, slot);
 		}
 	}
 	const uint64_t nslots = max_used + 1 + 256; // base + 255 is always a readable slot

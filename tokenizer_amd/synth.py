@@ -249,3 +249,32 @@ def pack_vocab(tokens):
 def pack_docs(texts):
     """list[bytes] -> (bytes u8[], doc_offsets u64[D+1])."""
     return pack_vocab(texts)
+
+
+def sample_vocab(corpus: np.ndarray, vocab_size: int, seed: int = 355, cp_lo: int = 2, cp_hi: int = 10):
+    """`vocab_size` distinct tokens of cp_lo..cp_hi code points cut
+    from the (ASCII-lower-cased) corpus itself at random code-point positions, so that deep trie
+    paths exist; then every single character of the corpus."""
+    rng = np.random.default_rng(seed)
+    b = np.ascontiguousarray(corpus, dtype=np.uint8).copy()
+    up = (b >= 65) & (b <= 90)
+    b[up] += 32
+    starts = np.flatnonzero((b & 0xC0) != 0x80)  # code-point starts
+    n = len(starts)
+    ends = np.append(starts, len(b))
+    raw = b.tobytes()
+    tokens, seen = [], set()
+    while len(tokens) < vocab_size and n > cp_hi:
+        want = vocab_size - len(tokens)
+        pos = rng.integers(0, n - cp_hi, size=want + want // 8 + 16)
+        ln = rng.integers(cp_lo, cp_hi + 1, size=len(pos))
+        for p, l in zip(pos.tolist(), ln.tolist()):
+            t = raw[int(ends[p]):int(ends[p + l])]
+            if b"\x00" in t or t in seen:
+                continue
+            seen.add(t)
+            tokens.append(t)
+            if len(tokens) == vocab_size:
+                break
+    singles = sorted({raw[int(ends[i]):int(ends[i + 1])] for i in rng.integers(0, n, size=min(n, 400_000)).tolist()} - seen) if n else []
+    return tokens + singles
