@@ -100,7 +100,7 @@ def test_score_matches_oracle_on_synthetic(kind, nbytes, V):
 
 
 def test_wide_vocabulary_uses_32bit_stream():
-    # V + 3 > 32767 forces 32-bit stream entries and two histogram id ranges
+    # V + 3 > 32767 forces 32-bit stream entries (one histogram id range up to 40,000 ids, several above)
     corpus, off = synth.random_utf8(1_000_000, seed=11, doc_lo=512, doc_hi=100_000)
     tokens = synth.build_vocab(corpus, 40000)
     # random text has too few repeated n-grams: top the list up with slices of the corpus

@@ -907,8 +907,10 @@ void launch_slab_reduce(const uint32_t *slab, uint32_t rows, uint32_t n_cols, un
 void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,
                       uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip) {
 	const uint32_t n_ids = V + 3;
-	const uint32_t range = std::min<uint32_t>(n_ids, 32768);
-	const uint32_t ranges = (n_ids + range - 1) / range;
+	// every id range is a pass over the whole stream: as few as the 160 KB of LDS allow, equal in size
+	constexpr uint32_t kMaxRange = 40000;
+	const uint32_t ranges = (n_ids + kMaxRange - 1) / kMaxRange;
+	const uint32_t range = (n_ids + ranges - 1) / ranges;
 	const uint32_t lds = range * 4;
 	if (plan.wide_ids) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_kernel<true>),
