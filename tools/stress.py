@@ -80,7 +80,7 @@ def main():
     del corpus
     # 3. random UTF-8, 128 k vocabulary (wide ids)
     corpus, off = synth.random_utf8(int(utf8_mb * 1e6), seed=355)
-    tokens = synth.build_vocab(corpus[: 4_000_000], 128000)
+    tokens = synth.sample_vocab(corpus[: 50_000_000], 128000)  # deep trie: tokens cut from the corpus itself
     s = ta.Scorer(0)
     tb, to = synth.pack_vocab(tokens)
     s.set_vocab(tb, to)
