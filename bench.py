@@ -25,6 +25,8 @@ import time
 
 import numpy as np
 
+os.environ["TOKSCORE_TIMING"] = "1"  # the roofline figure needs the library's per-kernel events inside the timed region
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -30,6 +30,15 @@ uint64_t env_u64(const char *name, uint64_t dflt) {
 	return strtoull(s, nullptr, 10);
 }
 
+// interval between two recorded events; 0 when both are the same event
+hipError_t elapsed_ms(float *ms, hipEvent_t a, hipEvent_t b) {
+	if (a == b) {
+		*ms = 0.0f;
+		return hipSuccess;
+	}
+	return hipEventElapsedTime(ms, a, b);
+}
+
 } // namespace
 
 struct tokscore_ctx {
@@ -43,6 +52,10 @@ struct tokscore_ctx {
 	// read the kernel durations afterwards without a host sync inside its timed region
 	static constexpr int kRing = 256;
 	hipEvent_t ring[kRing][5] = {};
+	// the events the timing code reads for a call: a full evaluation records three of its five
+	// (every record costs about 5 us of stream time) and reads 0 = 1, 3 = 2
+	hipEvent_t view[kRing][5] = {};
+	bool timing_on = true; // TOKSCORE_TIMING=0: no events at all
 	hipEvent_t *ev = ring[0];
 	uint64_t calls = 0;   // score calls enqueued
 	uint64_t drained = 0; // calls whose timings were handed out by tokscore_drain_timings
@@ -400,17 +413,29 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
 	ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
 	             c->d_chunk_state + 2 * (size_t)(c->nchunks + 1), c->nchunks};
-	c->ev = c->ring[c->calls % tokscore_ctx::kRing];
-	c->calls++;
-	HIP_TRY(c, hipEventRecord(c->ev[0], s));
 	// fix-up kernels only when some chunk starts at a speculated position
 	const bool repair = c->unsynced != 0;
+	// events: scan start, scan end, [fix-up forked,] end.  Each record holds the stream for about
+	// 5 us, so the evaluation start shares the scan-start event (prepare_kernel, 4 us, is outside)
+	// and without fix-up kernels the "fix-up" interval is empty.
+	hipEvent_t *ev = nullptr, *view = nullptr;
+	if (c->timing_on) {
+		ev = c->ring[c->calls % tokscore_ctx::kRing];
+		view = c->view[c->calls % tokscore_ctx::kRing];
+		c->calls++;
+		view[0] = view[1] = ev[1];
+		view[2] = ev[2];
+		view[3] = repair ? ev[3] : ev[2];
+		view[4] = ev[4];
+		c->ev = view;
+	}
+	auto mark = [&](int k) -> hipError_t { return ev ? hipEventRecord(ev[k], s) : hipSuccess; };
 	if (c->scan_path == 1) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s);
-		HIP_TRY(c, hipEventRecord(c->ev[1], s));
+		HIP_TRY(c, mark(1));
 		launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s);
-		HIP_TRY(c, hipEventRecord(c->ev[2], s));
+		HIP_TRY(c, mark(2));
 		if (repair) {
 			// the chunk-boundary fix-up (a few serial walks, latency bound) and the histogram of
 			// the token stream only share d_out, which both update with atomics: side by side
@@ -418,8 +443,8 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 			HIP_TRY(c, hipStreamWaitEvent(c->side, c->ev_fork, 0));
 			launch_fixup(T, C, S, d_out, c->side);
 			HIP_TRY(c, hipEventRecord(c->ev_join, c->side));
+			HIP_TRY(c, mark(3));
 		}
-		HIP_TRY(c, hipEventRecord(c->ev[3], s));
 		launch_histogram(Q, c->tile, (uint32_t)c->V, d_out, c->d_slab, c->slab_blocks, s);
 		if (repair) {
 			HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
@@ -427,16 +452,18 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		}
 	} else {
 		HIP_TRY(c, hipMemsetAsync(d_out, 0, (c->V + 5) * sizeof(unsigned long long), s));
-		HIP_TRY(c, hipEventRecord(c->ev[1], s));
+		HIP_TRY(c, mark(1));
 		launch_scan_generic(T, C, S, d_out, s);
-		HIP_TRY(c, hipEventRecord(c->ev[2], s));
-		if (repair) launch_fixup(T, C, S, d_out, s);
-		HIP_TRY(c, hipEventRecord(c->ev[3], s));
+		HIP_TRY(c, mark(2));
+		if (repair) {
+			launch_fixup(T, C, S, d_out, s);
+			HIP_TRY(c, mark(3));
+		}
 		launch_finalize(d_out, (uint32_t)c->V, c->D, c->total, s);
 	}
-	HIP_TRY(c, hipEventRecord(c->ev[4], s));
+	HIP_TRY(c, mark(4));
 	HIP_TRY(c, hipGetLastError());
-	c->timing_pending = true;
+	c->timing_pending = ev != nullptr;
 	return TOKSCORE_OK;
 }
 
@@ -523,6 +550,7 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	if (hipSetDevice(device) != hipSuccess) return TOKSCORE_E_NO_DEVICE;
 	tokscore_ctx *c = new tokscore_ctx();
 	c->device = device;
+	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -759,6 +787,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		             c->d_chunk_state + 2 * (size_t)(c->nchunks + 1), c->nchunks};
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 		c->ev = c->ring[c->calls % tokscore_ctx::kRing];
+		for (int k = 0; k < 5; k++) c->view[c->calls % tokscore_ctx::kRing][k] = c->ev[k];
 		c->calls++;
 		HIP_TRY(c, hipEventRecord(c->ev[0], s));
 		if (c->index_state == 0) build_index(c);
@@ -1028,10 +1057,10 @@ int tokscore_last_timing(tokscore_ctx *c, float ms[4]) {
 	if (c->timing_pending) {
 		(void)hipSetDevice(c->device);
 		HIP_TRY(c, hipEventSynchronize(c->ev[4]));
-		HIP_TRY(c, hipEventElapsedTime(&c->last_ms[0], c->ev[0], c->ev[4]));
-		HIP_TRY(c, hipEventElapsedTime(&c->last_ms[1], c->ev[1], c->ev[2]));
-		HIP_TRY(c, hipEventElapsedTime(&c->last_ms[2], c->ev[2], c->ev[3]));
-		HIP_TRY(c, hipEventElapsedTime(&c->last_ms[3], c->ev[3], c->ev[4]));
+		HIP_TRY(c, elapsed_ms(&c->last_ms[0], c->ev[0], c->ev[4]));
+		HIP_TRY(c, elapsed_ms(&c->last_ms[1], c->ev[1], c->ev[2]));
+		HIP_TRY(c, elapsed_ms(&c->last_ms[2], c->ev[2], c->ev[3]));
+		HIP_TRY(c, elapsed_ms(&c->last_ms[3], c->ev[3], c->ev[4]));
 		c->timing_pending = false;
 	}
 	memcpy(ms, c->last_ms, sizeof c->last_ms);
@@ -1046,12 +1075,12 @@ int tokscore_drain_timings(tokscore_ctx *c, float *ms, uint32_t cap, uint32_t *n
 	if (c->calls - first > (uint64_t)tokscore_ctx::kRing) first = c->calls - tokscore_ctx::kRing;
 	uint32_t k = 0;
 	for (uint64_t i = first; i < c->calls && k < cap; i++, k++) {
-		hipEvent_t *e = c->ring[i % tokscore_ctx::kRing];
+		hipEvent_t *e = c->view[i % tokscore_ctx::kRing];
 		HIP_TRY(c, hipEventSynchronize(e[4]));
-		HIP_TRY(c, hipEventElapsedTime(&ms[4 * k + 0], e[0], e[4]));
-		HIP_TRY(c, hipEventElapsedTime(&ms[4 * k + 1], e[1], e[2]));
-		HIP_TRY(c, hipEventElapsedTime(&ms[4 * k + 2], e[2], e[3]));
-		HIP_TRY(c, hipEventElapsedTime(&ms[4 * k + 3], e[3], e[4]));
+		HIP_TRY(c, elapsed_ms(&ms[4 * k + 0], e[0], e[4]));
+		HIP_TRY(c, elapsed_ms(&ms[4 * k + 1], e[1], e[2]));
+		HIP_TRY(c, elapsed_ms(&ms[4 * k + 2], e[2], e[3]));
+		HIP_TRY(c, elapsed_ms(&ms[4 * k + 3], e[3], e[4]));
 	}
 	c->drained = first + k;
 	*n = k;
