@@ -17,10 +17,11 @@ void launch_snap_chunks(const TrieDev &T, const CorpusDev &C, const uint64_t *be
                         uint32_t *synced, uint32_t nchunks, uint32_t max_len, uint32_t window, hipStream_t stream);
 // Incremental re-score: bit j of sel = 1 for every chunk that holds an occurrence of the byte string
 // tok[0 .. len) in the lower-cased corpus (chunks cut every chunk_bytes, each boundary moved
-// forward by less than chunk_bytes); launch_count_sel: n_sel[0] = number of selected chunks.
+// forward by less than chunk_bytes).
 void launch_find_token_chunks(const CorpusDev &C, const uint64_t *begin, uint32_t nchunks, uint64_t chunk_bytes,
                               const uint8_t *tok, uint32_t len, uint32_t *sel, hipStream_t stream);
-void launch_count_sel(const uint32_t *sel, uint32_t nchunks, uint32_t *n_sel, hipStream_t stream);
+// list[0 .. n) = the chunks whose bit is set in sel (any order), list[nchunks] = n
+void launch_compact_sel(const uint32_t *sel, uint32_t nchunks, uint32_t *list, hipStream_t stream);
 // Occurrence index, built once per plan: index[row][chunk bit] = string `row` occurs in the chunk
 // (slot_row[t] = row of the string that ends at slot t, or -1); row_chunks[row] = its chunk count.
 // launch_or_rows: sel = OR of up to 8 rows.  (sel is a chunk bitmap, (nchunks + 31) / 32 words.)
@@ -59,7 +60,7 @@ uint32_t stream_block_bytes(uint32_t wide_ids);
 bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num_cus, TileScanPlan *plan);
 void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S, const StreamDev &Q,
                       const TileScanPlan &plan, const uint64_t *chunk_first_doc, uint64_t max_len,
-                      hipStream_t stream, const uint32_t *chunk_sel = nullptr);
+                      hipStream_t stream, const uint32_t *sel_list = nullptr, const uint32_t *sel_count = nullptr);
 // Clears out[0 .. V+5), the stream cursor and fill words in one launch and presets
 // out[0] = out[1] = D (START / END once per document) and out[V+4] = total_bytes.
 // out == nullptr: leave the counts as they are (incremental re-score).

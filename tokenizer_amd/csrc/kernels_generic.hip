@@ -231,17 +231,27 @@ __global__ void __launch_bounds__(256) find_token_chunks_kernel(CorpusDev C, con
 	}
 }
 
-// n_sel[0] = number of selected chunks (bits set in sel[0 .. words)).  One block.
-__global__ void __launch_bounds__(1024) count_sel_kernel(const uint32_t *sel, uint32_t words, uint32_t *n_sel) {
+// chunk bitmap -> list of the selected chunk indices (any order) + their number in list[nchunks]:
+// the partial scan's work queue then runs over the list only instead of skipping through every
+// chunk of the corpus (one queue pull per chunk costs a wave about a microsecond)
+__global__ void __launch_bounds__(1024) compact_sel_kernel(const uint32_t *sel, uint32_t words, uint32_t nchunks,
+                                                           uint32_t *list) {
 	__shared__ uint32_t s_n;
 	if (threadIdx.x == 0) s_n = 0;
 	__syncthreads();
-	uint32_t n = 0;
-	for (uint32_t j = threadIdx.x; j < words; j += blockDim.x) n += (uint32_t)__builtin_popcount(sel[j]);
-	for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
-	if ((threadIdx.x & 63) == 0 && n) atomicAdd(&s_n, n);
+	for (uint32_t j = threadIdx.x; j < words; j += blockDim.x) {
+		uint32_t w = sel[j];
+		if (!w) continue;
+		uint32_t at = atomicAdd(&s_n, (uint32_t)__builtin_popcount(w));
+		while (w) {
+			const uint32_t chunk = j * 32 + (uint32_t)__builtin_ctz(w);
+			w &= w - 1;
+			if (chunk < nchunks && at < nchunks) list[at] = chunk;
+			at++;
+		}
+	}
 	__syncthreads();
-	if (threadIdx.x == 0) n_sel[0] = s_n;
+	if (threadIdx.x == 0) list[nchunks] = s_n < nchunks ? s_n : nchunks;
 }
 
 // --- occurrence index: which chunks does each vocabulary string occur in? ---------------
@@ -379,8 +389,8 @@ void launch_find_token_chunks(const CorpusDev &C, const uint64_t *begin, uint32_
 	                   len, sel);
 }
 
-void launch_count_sel(const uint32_t *sel, uint32_t nchunks, uint32_t *n_sel, hipStream_t stream) {
-	hipLaunchKernelGGL(count_sel_kernel, dim3(1), dim3(1024), 0, stream, sel, (nchunks + 31) / 32, n_sel);
+void launch_compact_sel(const uint32_t *sel, uint32_t nchunks, uint32_t *list, hipStream_t stream) {
+	hipLaunchKernelGGL(compact_sel_kernel, dim3(1), dim3(1024), 0, stream, sel, (nchunks + 31) / 32, nchunks, list);
 }
 
 void launch_index_all(const TrieDev &T, const CorpusDev &C, const int32_t *slot_row, const uint64_t *begin,

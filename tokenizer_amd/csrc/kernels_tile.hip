@@ -384,7 +384,7 @@ template <bool WIDE>
 __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C, ChunkState S, StreamDev Qd,
                                                          const uint64_t *chunk_first_doc, uint32_t seg_bytes,
                                                          uint32_t halo_bytes, uint32_t max_len, uint32_t wave_lds_bytes,
-                                                         uint64_t readable_end, const uint32_t *chunk_sel) {
+                                                         uint64_t readable_end, const uint32_t *sel_list, const uint32_t *sel_count) {
 	using Q = QTraits<WIDE>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const uint32_t lane = threadIdx.x & 63;
@@ -429,6 +429,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	const unsigned long long prof_start = prof_t;
 	(void)prof_acc, (void)prof_t, (void)prof_start;
 	const uint32_t queue = blockIdx.x % kWorkQueues;
+	const uint32_t n_work = sel_list ? sel_count[0] : S.nchunks; // chunks in the queue
 	const uint32_t min_seg = 4 * (((max_len + 4 + 3) / 4) | 1u); // shortest legal lane segment
 	constexpr int kMaxVec = 7; // register prefetch depth: up to 7 x 16 B per lane
 	const bool reg_prefetch = n_vec <= 64 * kMaxVec;
@@ -440,8 +441,8 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 		uint32_t j = 0;
 		if (lane == 0) j = atomicAdd(&Qd.cursor[kQueueHeadWord + queue * kQueueHeadStride], 1u);
 		j = __builtin_amdgcn_readfirstlane(j) * kWorkQueues + queue;
-		if (j >= S.nchunks) break;
-		if (chunk_sel && !((chunk_sel[j >> 5] >> (j & 31)) & 1u)) continue; // incremental re-score: only the selected chunks
+		if (j >= n_work) break;
+		if (sel_list) j = sel_list[j]; // incremental re-score: the queue runs over the selected chunks only
 		PROF_ADD(0, prof_t); // queue
 		prof_acc[7]++;
 		const uint64_t begin = S.begin[j];
@@ -871,7 +872,7 @@ bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num
 
 void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S, const StreamDev &Q,
                       const TileScanPlan &plan, const uint64_t *chunk_first_doc, uint64_t max_len,
-                      hipStream_t stream, const uint32_t *chunk_sel) {
+                      hipStream_t stream, const uint32_t *sel_list, const uint32_t *sel_count) {
 	const uint32_t halo = (uint32_t)((max_len + 15) & ~15ull);
 	const uint32_t wave_bytes = (plan.lds_bytes - plan.lds_slots * 8) / plan.waves_per_block;
 	const uint64_t readable_end = (C.total + 256) & ~15ull;
@@ -882,13 +883,13 @@ void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S,
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
 		hipLaunchKernelGGL(scan_tile_kernel<true>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes,
 		                   stream, Tl, C, S, Q, chunk_first_doc, plan.seg_bytes, halo, (uint32_t)max_len, wave_bytes,
-		                   readable_end, chunk_sel);
+		                   readable_end, sel_list, sel_count);
 	} else {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_tile_kernel<false>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
 		hipLaunchKernelGGL(scan_tile_kernel<false>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes,
 		                   stream, Tl, C, S, Q, chunk_first_doc, plan.seg_bytes, halo, (uint32_t)max_len, wave_bytes,
-		                   readable_end, chunk_sel);
+		                   readable_end, sel_list, sel_count);
 	}
 }
 

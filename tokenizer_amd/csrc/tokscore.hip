@@ -55,7 +55,8 @@ struct tokscore_ctx {
 	// the events the timing code reads for a call: a full evaluation records three of its five
 	// (every record costs about 5 us of stream time) and reads 0 = 1, 3 = 2
 	hipEvent_t view[kRing][5] = {};
-	bool timing_on = true; // TOKSCORE_TIMING=0: no events at all
+	bool timing_on = true;      // TOKSCORE_TIMING=0: no events at all
+	bool timing_detail = false; // TOKSCORE_TIMING=2: the incremental re-score records its passes too
 	hipEvent_t *ev = ring[0];
 	uint64_t calls = 0;   // score calls enqueued
 	uint64_t drained = 0; // calls whose timings were handed out by tokscore_drain_timings
@@ -106,7 +107,8 @@ struct tokscore_ctx {
 	uint32_t nchunks = 0;
 	uint32_t unsynced = 0; // chunks whose entry is speculated (not at a guaranteed token start)
 	bool uniform_chunks = false; // boundaries at multiples of chunk_bytes, each moved forward by < chunk_bytes
-	uint32_t *d_sel = nullptr;   // chunk bitmap of an incremental re-score, + 1 word: the number of bits set
+	uint32_t *d_sel = nullptr;   // chunk bitmap of an incremental re-score
+	uint32_t *d_sel_list = nullptr; // the selected chunks as a list [nchunks] + 1 word: their number
 	// occurrence index (one bit per string and chunk), built by the first incremental re-score of a plan
 	uint32_t *d_index = nullptr;
 	int index_state = 0; // 0 not tried, 1 built, -1 not available (too large / allocation failed)
@@ -173,6 +175,8 @@ void free_plan(tokscore_ctx *c) {
 	c->d_fill = nullptr;
 	if (c->d_sel) (void)hipFree(c->d_sel);
 	c->d_sel = nullptr;
+	if (c->d_sel_list) (void)hipFree(c->d_sel_list);
+	c->d_sel_list = nullptr;
 	if (c->d_index) (void)hipFree(c->d_index);
 	c->d_index = nullptr;
 	c->index_state = 0;
@@ -352,6 +356,7 @@ int ensure_plan(tokscore_ctx *c) {
 	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, kCursorWords * sizeof(uint32_t)));
 	HIP_TRY(c, hipMalloc((void **)&c->d_sel, ((size_t)(c->nchunks + 31) / 32 + 1) * sizeof(uint32_t)));
+	HIP_TRY(c, hipMalloc((void **)&c->d_sel_list, ((size_t)c->nchunks + 1) * sizeof(uint32_t)));
 	if (c->scan_path == 1) {
 		// Token stream: one entry per emitted token plus the repair rounds' +/- entries, in
 		// log blocks that are partly empty.  3 entries per corpus byte is far above anything
@@ -551,6 +556,7 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	tokscore_ctx *c = new tokscore_ctx();
 	c->device = device;
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
+	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -786,10 +792,21 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
 		             c->d_chunk_state + 2 * (size_t)(c->nchunks + 1), c->nchunks};
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
-		c->ev = c->ring[c->calls % tokscore_ctx::kRing];
-		for (int k = 0; k < 5; k++) c->view[c->calls % tokscore_ctx::kRing][k] = c->ev[k];
-		c->calls++;
-		HIP_TRY(c, hipEventRecord(c->ev[0], s));
+		// events: start and end; with TOKSCORE_TIMING=2 also the subtract pass, the slot patch and
+		// the add pass (every record holds the stream for about 5 us)
+		hipEvent_t *ev = nullptr;
+		if (c->timing_on) {
+			ev = c->ring[c->calls % tokscore_ctx::kRing];
+			hipEvent_t *view = c->view[c->calls % tokscore_ctx::kRing];
+			for (int k = 0; k < 5; k++) view[k] = c->timing_detail ? ev[k] : ev[k == 4 ? 4 : 0];
+			c->calls++;
+			c->ev = view;
+		}
+		bool listed = false; // d_sel_list holds the selected chunks
+		auto mark = [&](int k) -> hipError_t {
+			return ev && (c->timing_detail || k == 0 || k == 4) ? hipEventRecord(ev[k], s) : hipSuccess;
+		};
+		HIP_TRY(c, mark(0));
 		if (c->index_state == 0) build_index(c);
 		const uint32_t limit = c->nchunks / (uint32_t)std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)); // beyond this two partial passes cost what a full evaluation does
 		if (c->index_state == 1) {
@@ -805,7 +822,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 				}
 			}
 			if (nsel > limit) {
-				c->calls--; // this call's event set goes to the full evaluation
+				if (ev) c->calls--; // this call's event set goes to the full evaluation
 				return tokscore_score(c, counts, total_tokens, total_bytes);
 			}
 			if (nsel) launch_or_rows(c->d_index, rows, nrows, c->nchunks, c->d_sel, s);
@@ -820,34 +837,41 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 				launch_find_token_chunks(C, c->d_chunk_begin, c->nchunks, c->chunk_bytes,
 				                         c->d_vocab_bytes + c->h_vocab_off[tok], (uint32_t)len, c->d_sel, s);
 			}
-			uint32_t *d_n = c->d_sel + (c->nchunks + 31) / 32;
-			launch_count_sel(c->d_sel, c->nchunks, d_n, s);
-			HIP_TRY(c, hipMemcpyAsync(&nsel, d_n, sizeof nsel, hipMemcpyDeviceToHost, s));
+			launch_compact_sel(c->d_sel, c->nchunks, c->d_sel_list, s);
+			listed = true;
+			HIP_TRY(c, hipMemcpyAsync(&nsel, c->d_sel_list + c->nchunks, sizeof nsel, hipMemcpyDeviceToHost, s));
 			HIP_TRY(c, hipStreamSynchronize(s));
 			if (nsel > limit) {
-				c->calls--;
+				if (ev) c->calls--;
 				return tokscore_score(c, counts, total_tokens, total_bytes);
 			}
 		}
-		HIP_TRY(c, hipEventRecord(c->ev[1], s));
+		// the scan hands out no more stream batches than it takes chunks, and a wave of the
+		// histogram takes whole batches (any grid is correct): no more histogram workgroups, and
+		// slab rows to add up, than that needs
+		if (nsel && !listed) launch_compact_sel(c->d_sel, c->nchunks, c->d_sel_list, s);
+		const uint32_t hist_blocks = std::max<uint32_t>(1, std::min<uint32_t>(c->slab_blocks, (nsel + 15) / 16));
+		HIP_TRY(c, mark(1));
 		if (nsel) {
 			launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s);
-			launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s, c->d_sel);
-			launch_histogram(Q, c->tile, (uint32_t)c->V, c->d_out, c->d_slab, c->slab_blocks, s, /*flip=*/true);
+			launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s, c->d_sel_list,
+			                 c->d_sel_list + c->nchunks);
+			launch_histogram(Q, c->tile, (uint32_t)c->V, c->d_out, c->d_slab, hist_blocks, s, /*flip=*/true);
 		}
-		HIP_TRY(c, hipEventRecord(c->ev[2], s));
+		HIP_TRY(c, mark(2));
 		c->state_valid = false; // until the second half is in
 		int st = apply_pending(c, s);
 		if (st) return st;
-		HIP_TRY(c, hipEventRecord(c->ev[3], s));
+		HIP_TRY(c, mark(3));
 		if (nsel) {
 			launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s);
-			launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s, c->d_sel);
-			launch_histogram(Q, c->tile, (uint32_t)c->V, c->d_out, c->d_slab, c->slab_blocks, s, /*flip=*/false);
+			launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s, c->d_sel_list,
+			                 c->d_sel_list + c->nchunks);
+			launch_histogram(Q, c->tile, (uint32_t)c->V, c->d_out, c->d_slab, hist_blocks, s, /*flip=*/false);
 		}
-		HIP_TRY(c, hipEventRecord(c->ev[4], s));
+		HIP_TRY(c, mark(4));
 		HIP_TRY(c, hipGetLastError());
-		c->timing_pending = true;
+		c->timing_pending = ev != nullptr;
 	}
 	int st = fetch_out(c, s);
 	if (st) return st;
