@@ -59,7 +59,8 @@ def run(tokens, corpus, off, moves, seed, paired=False, verify=0):
     dt = float(np.sum(wall))
     tm = np.array(s.drain_timings())
     if len(tm):
-        # an incremental evaluation records: whole | subtract pass | slot patch | add pass
+        # an incremental evaluation records: whole | subtract pass | slot patch | add pass (the three
+        # passes only with TOKSCORE_TIMING=2; by default just start and end, two events fewer per pass)
         # (a fallback to a full evaluation leaves other entries behind: keep the short ones)
         short = tm[tm[:, 0] < 0.35]
         if len(short):
