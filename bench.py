@@ -128,6 +128,43 @@ def moves_per_sec(scorer, tokens, corpus, off):
             "note": "moves/s; GPU: this shard and vocabulary, result on the host after every move"}
 
 
+def two_in_flight(first, tokens, corpus, off, dev, steps):
+    """Outside the timed region and not the headline: the same shard scored for two candidate
+    vocabularies at a time, one context and one stream each, so that one evaluation's histogram
+    and the tail of its scan overlap the other's scan (what an annealer that evaluates two
+    candidates concurrently gets).  Both results are checked against the synchronous call."""
+    import torch
+    import tokenizer_amd as ta
+    from tokenizer_amd import synth
+    second = ta.Scorer(dev.index or 0)
+    try:
+        second.set_vocab(*synth.pack_vocab(tokens))
+        second.set_corpus(corpus, off)
+        second.toggle(100, False)  # the other candidate: one token fewer
+        scorers = [first, second]
+        ref = [s.score() for s in scorers]
+        outs = [torch.zeros(len(tokens) + 5, dtype=torch.int64, device=dev) for _ in scorers]
+        streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        dt = 0.0
+        for n in (3, steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                for k in range(2):
+                    scorers[k].score_async(outs[k].data_ptr(), streams[k].cuda_stream)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        exact = True
+        for k in range(2):
+            got = outs[k].cpu().numpy().view(np.uint64)
+            exact = exact and bool(np.array_equal(got[:len(tokens) + 3], ref[k][0])) and int(got[len(tokens) + 3]) == ref[k][1]
+        return {"value": len(corpus) * 2 * steps / dt / 1e9, "unit": "GB/s", "ms_per_evaluation": dt * 1e3 / (2 * steps),
+                "evaluations": 2 * steps, "exact": exact,
+                "note": "two contexts on two streams, same shard; not the headline (one evaluation per step)"}
+    finally:
+        second.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -244,6 +281,7 @@ def main():
             "total_tokens": int(host[V + 3]), "h2d_inclusive_GBps": info.corpus_bytes / (h2d_s + elapsed / args.steps) / 1e9,
         }
         if world == 1 and not args.no_cpu:
+            rec["two_evaluations_in_flight"] = two_in_flight(scorer, tokens, corpus, off, dev, args.steps)
             rec["cpu_baseline"] = cpu_baseline(corpus, off, tokens)
             rec["annealing_moves_per_s"] = moves_per_sec(scorer, tokens, corpus, off)
         print(json.dumps(rec))
