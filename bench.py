@@ -33,7 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(corpus, off, tokens, sample_bytes=32_000_000):
+def cpu_baseline(corpus, off, tokens, sample_bytes=100_000_000):  # the whole bench shard: about 10 s of CPU work
     """Reference CPU path on the host cores, on the first ~sample_bytes of the shard."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from tokenizer_amd import synth
