@@ -371,6 +371,7 @@ int ensure_plan(tokscore_ctx *c) {
 		HIP_TRY(c, hipMalloc(&c->d_stream, batches * kStreamBatch * block_bytes));
 		HIP_TRY(c, hipMalloc((void **)&c->d_fill, batches * sizeof(uint32_t)));
 		c->slab_blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, c->total / (256 * 1024)));
+		c->slab_blocks = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, env_u64("TOKSCORE_SLAB_BLOCKS", c->slab_blocks)));
 		HIP_TRY(c, hipMalloc((void **)&c->d_slab, (size_t)c->slab_blocks * (c->V + 4) * sizeof(uint32_t)));
 	}
 	c->plan_valid = true;
