@@ -57,7 +57,12 @@ CONFIGS = [
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_LDS_SLOTS": "300"},   # most trie lookups fall through to L2
     {"TOKSCORE_SCAN": "generic", "TOKSCORE_CHUNK": "64", "TOKSCORE_NOSNAP": "1"},  # boundaries left mid-token: fix-up kernels
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "300", "TOKSCORE_NOSNAP": "1"},
+    {"TOKSCORE_SCAN": "stream"},                               # one byte stream per lane, trie image in LDS (the default)
+    {"TOKSCORE_SCAN": "stream", "TOKSCORE_STREAM": "64", "TOKSCORE_SPC": "3"},    # shortest streams, ragged chunks
+    {"TOKSCORE_SCAN": "stream", "TOKSCORE_STREAM": "1000", "TOKSCORE_WAVES": "4"},
 ]
+# goldens whose text has sync points and whose trie fits LDS: the stream scan must be the path taken
+STREAM_CASES = {"ascii_caps", "cjk_heavy", "short_docs", "prefix_greedy"}  # (wiki_annealed: 125k trie nodes, random_utf8: > 125 edge labels: tile scan)
 
 
 @pytest.mark.parametrize("cfg", range(len(CONFIGS)))
@@ -73,6 +78,8 @@ def test_score_matches_reference_golden(case, cfg):
     assert bad.size == 0, (case, CONFIGS[cfg], bad[:10], counts[bad[:10]], exp["counts_vec"][bad[:10]])
     if CONFIGS[cfg]["TOKSCORE_SCAN"] == "tile":
         assert info.scan_path == 1, "tile scan was expected to be selected"
+    if CONFIGS[cfg]["TOKSCORE_SCAN"] == "stream" and case in STREAM_CASES:
+        assert info.scan_path == 2, "stream scan was expected to be selected"
 
 
 @pytest.mark.parametrize("case", [c for c in O.golden_cases() if "ids" in O.load_golden(c)["expected"]])
@@ -93,7 +100,7 @@ def test_score_matches_oracle_on_synthetic(kind, nbytes, V):
     tokens = synth.build_vocab(corpus[:min(nbytes, 1_000_000)], V)
     voc = O.OracleVocab(*synth.pack_vocab(tokens))
     exp_counts, exp_tt, exp_tb = voc.score(corpus, off, threads=8)
-    for cfg in ({"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "generic"}):
+    for cfg in ({"TOKSCORE_SCAN": "stream"}, {"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "generic"}):
         (counts, tt, tb), info = _score_with(cfg, tokens, corpus, off)
         assert (tt, tb) == (exp_tt, exp_tb), (kind, cfg)
         assert np.array_equal(counts, exp_counts), (kind, cfg)
@@ -142,7 +149,7 @@ def test_empty_and_tiny_corpora():
         corpus, off = synth.pack_docs(docs)
         voc = O.OracleVocab(*synth.pack_vocab(tokens))
         exp = voc.score(corpus, off)
-        for cfg in ({"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "generic"}):
+        for cfg in ({}, {"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "generic"}):
             (counts, tt, tb), _ = _score_with(cfg, tokens, corpus, off)
             assert (tt, tb) == exp[1:], (docs, cfg)
             assert np.array_equal(counts, exp[0]), (docs, cfg)
@@ -161,14 +168,17 @@ def test_long_tokens_fall_back_to_generic_scan():
     assert (tt, tb) == exp[1:] and np.array_equal(counts, exp[0])
 
 
-def test_toggle_equals_full_rescore_of_the_toggled_vocabulary():
+@pytest.mark.parametrize("path", ["stream", "tile"])
+def test_toggle_equals_full_rescore_of_the_toggled_vocabulary(path):
     corpus, off = synth.cjk_heavy(400_000, seed=9)
     tokens = synth.build_vocab(corpus[:200_000], 9000)
     V = len(tokens)
-    s = ta.Scorer(0)
+    s, old = _scorer({"TOKSCORE_SCAN": path})
     s.set_vocab(*synth.pack_vocab(tokens))
     s.set_corpus(corpus, off)
     base = s.score()
+    _restore(old)
+    assert s.info().scan_path == (2 if path == "stream" else 1)
     rng = np.random.default_rng(5)
     enabled = np.ones(V, dtype=bool)
     multi = [i for i, t in enumerate(tokens) if len(t.decode("utf-8")) > 1]
@@ -220,8 +230,9 @@ def test_reference_flow_through_file_mirrors(case):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("path", ["stream", "tile"])
 @pytest.mark.parametrize("index_mb", ["2048", "0"])  # with the occurrence index / by searching the corpus
-def test_incremental_rescore_paths(index_mb):
+def test_incremental_rescore_paths(index_mb, path):
     """tokscore_score_incremental: several toggles per re-score, a token that occurs nearly
     everywhere (falls back to a full evaluation), a tokenize call between toggle and re-score,
     re-score without toggles -- always equal to a full evaluation of the toggled vocabulary."""
@@ -240,12 +251,14 @@ def test_incremental_rescore_paths(index_mb):
 
     old_env = os.environ.get("TOKSCORE_INDEX_MB")
     os.environ["TOKSCORE_INDEX_MB"] = index_mb
-    s = ta.Scorer(0)
+    s, old_scan = _scorer({"TOKSCORE_SCAN": path})
     try:
         s.set_vocab(*synth.pack_vocab(tokens))
         s.set_corpus(corpus, off)
         enabled = np.ones(V, dtype=bool)
         base = s.score()
+        _restore(old_scan)
+        assert s.info().scan_path == (2 if path == "stream" else 1)
         assert same(base, expect(enabled))
         assert same(s.score(incremental=True), base)              # nothing toggled
         rare = V - 1

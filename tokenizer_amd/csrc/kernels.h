@@ -75,6 +75,50 @@ void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, 
 void launch_slab_reduce(const uint32_t *slab, uint32_t rows, uint32_t n_cols, unsigned long long *counts,
                         hipStream_t stream);
 
+// kernels_stream.hip -- stream scan: one independent byte stream per lane, the whole trie in LDS
+struct StreamTrieDev {      // trie.h: StreamImage
+	const uint8_t *lt;     // [nslots padded to 16] label code | 0x80 = a token ends here
+	const uint16_t *base;  // [nslots padded to 8]
+	uint32_t nslots;
+	uint32_t root_base;
+};
+struct ByteCodes {
+	uint8_t code[256];     // byte -> code (StreamImage::code)
+};
+struct StreamWork {
+	const uint8_t *prep;       // prepared corpus: codes of the lower-cased bytes, code 0 after every document
+	const uint32_t *pbeg;      // [nstreams + 1] stream boundaries (prepared offsets), all guaranteed token starts
+	uint32_t nstreams;
+	uint32_t prep_total;       // bytes of the prepared corpus
+	uint32_t range_bytes;      // full evaluation: the corpus in nranges equal ranges, one lane each ...
+	uint32_t nranges;
+	uint32_t *entry;           // ... [nranges] entry overshoot the range's counted chain starts with
+	uint32_t *exit_a;          // ... [nranges] exit overshoot, written by the scan
+	const uint32_t *sel_list;  // incremental re-score: selected chunks (or nullptr) ...
+	const uint32_t *sel_count; // ... and their number
+	const uint32_t *chunk_first; // [nchunks + 1] first stream of every chunk
+	uint32_t streams_per_chunk;  // upper bound of the streams in one chunk
+};
+struct StreamScanPlan {
+	uint32_t ring;            // bytes of a lane's LDS ring (64 or 128)
+	uint32_t waves_per_block;
+	uint32_t blocks;
+	uint32_t lds_bytes;
+};
+void launch_prep_corpus(const CorpusDev &C, const ByteCodes &M, uint8_t *prep, uint64_t prep_total, uint32_t *flags,
+                        hipStream_t stream);
+bool plan_stream_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan);
+void launch_scan_stream(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
+                        hipStream_t stream);
+// out[slot_id[s]] += occurrences of slot s in the stream, out[total_index] += entries on counted slots
+void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
+                            uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip = false);
+// After a full-evaluation scan: repairs the ranges whose entry was not the previous range's exit
+// (counts straight into out), leaves the true entries in W.entry.  changed: one word, zero on entry.
+void launch_fixup_stream(const StreamTrieDev &T, const uint32_t *slot_id, const StreamWork &W, uint32_t *exit_b,
+                         uint32_t *changed, unsigned long long *out, uint32_t total_index, hipStream_t stream);
+uint64_t stream_scan_capacity_batches(uint64_t prep_total, uint32_t waves_total);
+
 // kernels_count.hip -- closed-vocabulary all-occurrence counting (GetTokens.cpp:21-27)
 struct CountPlan {
 	uint32_t halo;      // bytes staged past a tile (longest walk + slack)

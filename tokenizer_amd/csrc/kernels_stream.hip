@@ -1,0 +1,561 @@
+// kernels_stream.hip -- the hot path since round 2: exact greedy segmentation with one
+// independent byte stream per lane and the whole trie in LDS.
+//
+// What changed against the LDS-tile scan (kernels_tile.hip, still the path for vocabularies
+// whose trie does not fit): the serial dependency of SolutionFile::Tokenize
+// (/root/reference/src/files/SolutionFile.cpp:89-97) is no longer broken inside a wave by
+// speculation and repair.  Instead every LANE owns a contiguous range of the corpus and walks one
+// chain from its first token to its last.  Full evaluation: the corpus is cut into equal ranges, one
+// per lane of the grid, and lane g starts at the entry it was found to have in the PREVIOUS
+// evaluation (entry[g] = overshoot of the chain coming in from range g - 1; zero before the first).
+// It writes its own exit overshoot; wherever exit[g - 1] != entry[g] -- everywhere in the first
+// evaluation of a plan, near the occurrences of a toggled token afterwards, nowhere while the
+// vocabulary stays as it is -- fixup_parallel_stream_kernel dual-walks the true chain (+1) against
+// the counted one (-1) until they meet, and stores the true entry for the next evaluation.
+// Incremental re-score: lanes take the streams of the selected chunks, which begin and end at
+// guaranteed token starts (snap_chunks_kernel: a position no trie path reaches across, or a
+// document start) and need no entries.  What the corpus needs is done once per corpus + vocabulary
+// (at plan time, prep_corpus_kernel) instead of per evaluation:
+//   * lower-casing (SolutionFile.cpp:87-88);
+//   * document ends: a separator (code 0) is stored after every document.  Documents hold no NUL
+//     (DataFile.cpp:27-29; checked, else the tile path is used), the stream image of the trie has
+//     no edge labelled 0 below the root, so no match crosses a document end (the window clip of
+//     SolutionFile.cpp:90) and the hot loop has no limit compare at all; the separator itself is
+//     consumed as a one-byte token whose slot nobody counts;
+//   * bytes become 7-bit codes (trie.h: StreamImage): the bytes that label a trie edge keep a code
+//     of their own, all others share one -- that frees the label's eighth bit for "a token ends
+//     here", which is what lets a trie slot be 3 bytes.
+// A lane keeps the next bytes of its range in a small ring in LDS (64 or 128 bytes, refilled 16
+// bytes at a time, the load of one round lands while the next round's lookups run), the trie is
+// the 3-byte-per-slot stream image (trie.h: StreamImage), entirely in LDS, and a token is logged
+// as the 16-bit index of the slot it ended on; hist_slots_kernel bins slot indices and
+// slab_reduce_map_kernel turns slots into ids once per evaluation.
+#include "kernels.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace tokscore {
+
+namespace {
+
+#define LDS_AS __attribute__((address_space(3)))
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_fence() {
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint32_t uni32(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ unsigned long long uni64(unsigned long long x) {
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+	const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+	return ((unsigned long long)hi << 32) | lo;
+}
+
+// A-Z -> a-z on four packed bytes (bytes >= 0x80 untouched).
+__device__ __forceinline__ uint32_t lower4(uint32_t x) {
+	const uint32_t low7 = x & 0x7F7F7F7Fu;
+	const uint32_t ge_A = low7 + 0x3F3F3F3Fu;
+	const uint32_t gt_Z = low7 + 0x25252525u;
+	const uint32_t is_up = ge_A & ~gt_Z & ~x & 0x80808080u;
+	return x | (is_up >> 2);
+}
+
+// ---- prepared corpus ---------------------------------------------------------------------
+// prep[off[d] + d .. off[d+1] + d) = document d lower-cased, prep[off[d+1] + d] = 0.  One thread
+// per 16 output bytes.  flags[0] != 0 afterwards: some document holds a NUL byte.
+__global__ void __launch_bounds__(256) prep_corpus_kernel(CorpusDev C, ByteCodes M, uint8_t *prep, uint64_t prep_total,
+                                                          uint32_t *flags) {
+	__shared__ uint8_t s_code[256];
+	s_code[threadIdx.x] = M.code[threadIdx.x]; // blockDim.x == 256
+	__syncthreads();
+	const uint64_t nvec = (prep_total + 15) / 16;
+	for (uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t q0 = v * 16;
+		// document of output byte q0: the last d with off[d] + d <= q0
+		uint64_t lo = 0, hi = C.D; // answer in [0, D - 1]; D >= 1 here
+		while (lo + 1 < hi) {
+			const uint64_t mid = (lo + hi) >> 1;
+			if (C.off[mid] + mid <= q0) lo = mid;
+			else hi = mid;
+		}
+		uint64_t d = lo;
+		uint64_t dend = C.off[d + 1] + d; // position of document d's separator
+		uint32_t w[4] = {0, 0, 0, 0};
+		bool nul = false;
+		for (uint32_t k = 0; k < 16; k++) {
+			const uint64_t q = q0 + k;
+			if (q >= prep_total) break;
+			while (q > dend) {
+				d++;
+				dend = C.off[d + 1] + d;
+			}
+			uint32_t c = 0;
+			if (q < dend) {
+				c = C.bytes[q - d];
+				nul = nul || c == 0;
+				c = s_code[lower8(c)];
+			}
+			w[k >> 2] |= c << (8 * (k & 3));
+		}
+		*reinterpret_cast<u32x4 *>(prep + q0) = u32x4{w[0], w[1], w[2], w[3]};
+		if (nul) flags[0] = 1u;
+	}
+}
+
+// ---- the scan ------------------------------------------------------------------------------
+constexpr uint32_t kLogEntries = 512;               // u16 entries per wave log block = one stream block (1 KiB)
+constexpr uint32_t kLogHigh = kLogEntries - 64;     // flush above this fill
+constexpr uint32_t kRound = 16;                     // lookups between two ring refills
+
+struct WaveLog {
+	LDS_AS uint16_t *cells;
+	uint32_t cur;   // wave uniform: entries used
+	uint32_t batch; // wave uniform
+	uint32_t used;  // wave uniform: blocks written in the current batch
+	__device__ __forceinline__ void clear(uint32_t lane) {
+		LDS_AS uint32_t *w = (LDS_AS uint32_t *)cells;
+		for (uint32_t i = lane; i < kLogEntries / 2; i += 64) w[i] = 0xFFFFFFFFu;
+		cur = 0;
+	}
+	__device__ __forceinline__ void init(LDS_AS uint16_t *c, uint32_t lane) {
+		cells = c;
+		batch = 0xFFFFFFFFu;
+		used = kStreamBatch;
+		clear(lane);
+	}
+	// wave-uniform call: the lanes with `pred` append `val`
+	__device__ __forceinline__ void put(bool pred, uint32_t val) {
+		const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+		if (pred) {
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+			cells[cur + rank] = (uint16_t)val;
+		}
+		cur += (uint32_t)__builtin_popcountll(m);
+	}
+	__device__ __forceinline__ void flush(const StreamDev &S, uint32_t lane) {
+		constexpr uint32_t vecs = kLogEntries * 2 / 16;
+		if (used == kStreamBatch) {
+			if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = kStreamBatch;
+			uint32_t b = 0;
+			if (lane == 0) b = atomicAdd(&S.cursor[0], 1u);
+			batch = __builtin_amdgcn_readfirstlane(b);
+			used = 0;
+			// cannot happen: the stream is sized for one entry per prepared byte; reported all the same
+			if (batch >= S.capacity_batches && lane == 0) S.cursor[1] = 1u;
+		}
+		wave_fence();
+		if (batch < S.capacity_batches) {
+			const LDS_AS u32x4 *src = (const LDS_AS u32x4 *)cells;
+			u32x4 *dst = reinterpret_cast<u32x4 *>(S.blocks) + ((size_t)batch * kStreamBatch + used) * vecs;
+			for (uint32_t i = lane; i < vecs; i += 64) dst[i] = src[i];
+		}
+		used++;
+		wave_fence();
+		clear(lane);
+		wave_fence();
+	}
+	__device__ __forceinline__ void finish(const StreamDev &S, uint32_t lane) {
+		if (cur != 0) flush(S, lane);
+		if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = used;
+	}
+};
+
+// One lookup for the lanes in `act` (see the file comment).  Walker state per lane:
+//   cp    prepared offset of the byte looked up next
+//   nb    base of the current trie node
+//   lend  offset just past the longest token found so far from the current start
+//   lslot the slot that token ended on
+// The root row is dense and all token ends, so the first lookup of a token always sets lend /
+// lslot; they need no reset between tokens.
+// Ring invariant (RING >= 2 * kRound + 14 + max_len, plan_stream_scan): at the start of a round
+// fill - cp > kRound and lend >= fill - RING, where [fill - RING, fill) is what the ring holds.
+template <uint32_t RING>
+__global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, StreamWork W, StreamDev Qd) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char stream_smem[];
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)stream_smem;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = uni32(threadIdx.x >> 6);
+	const uint32_t waves = blockDim.x >> 6;
+
+	// ---- stage the trie image: lt[] then base[] (both padded to 16 bytes by the host) ----
+	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
+	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
+	{
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
+		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		dst = (LDS_AS u32x4 *)(lds + label_bytes);
+		src = reinterpret_cast<const u32x4 *>(T.base);
+		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+	}
+	__syncthreads();
+	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
+	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
+
+	LDS_AS unsigned char *wbase = lds + label_bytes + info_bytes + wave * (64 * RING + kLogEntries * 2);
+	LDS_AS unsigned char *ring = wbase + lane * RING;
+	WaveLog log;
+	log.init((LDS_AS uint16_t *)(wbase + 64 * RING), lane);
+
+	const uint32_t total_lanes = gridDim.x * waves * 64;
+	const uint32_t gl = (blockIdx.x * waves + wave) * 64 + lane;
+	uint32_t n_items;
+	if (W.sel_list) n_items = W.sel_count[0] * W.streams_per_chunk; // incremental re-score: the selected chunks' streams
+	else n_items = W.nranges;                                       // full evaluation: equal ranges
+
+	for (uint32_t item = gl; __builtin_amdgcn_ballot_w64(item < n_items) != 0; item += total_lanes) {
+		uint32_t beg = 0, end = 0;
+		if (item < n_items) {
+			if (W.sel_list) {
+				uint32_t s0, s1;
+				const uint32_t chunk = W.sel_list[item / W.streams_per_chunk];
+				s0 = W.chunk_first[chunk] + item % W.streams_per_chunk;
+				s1 = s0 + 1;
+				if (s0 >= W.chunk_first[chunk + 1]) s0 = s1 = W.nstreams; // fewer streams in this chunk
+				if (s0 > W.nstreams) s0 = W.nstreams;
+				if (s1 > W.nstreams) s1 = W.nstreams;
+				beg = W.pbeg[s0];
+				end = W.pbeg[s1];
+			} else {
+				beg = item * W.range_bytes;
+				end = beg + W.range_bytes < W.prep_total ? beg + W.range_bytes : W.prep_total;
+				beg += W.entry[item]; // (may lie at or past `end`: the chain jumps the whole range)
+			}
+		}
+		const bool has_range = !W.sel_list && item < n_items;
+		bool active = beg < end;
+		uint32_t cp = beg, lend = beg, lslot = 0, nb = T.root_base;
+		uint32_t fill = beg & ~15u;
+		wave_fence();
+		if (active) {
+#pragma unroll
+			for (uint32_t k = 0; k < RING / 16; k++) {
+				const u32x4 x = *reinterpret_cast<const u32x4 *>(W.prep + fill);
+				*(LDS_AS u32x4 *)(ring + (fill & (RING - 1))) = x;
+				fill += 16;
+			}
+		}
+		wave_fence();
+		bool req = false;
+		u32x4 data = {0, 0, 0, 0};
+		unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+		while (act != 0) {
+			// ---- ring refill: what was asked for a round ago lands, the next 16 bytes are asked for ----
+			if (req) {
+				*(LDS_AS u32x4 *)(ring + (fill & (RING - 1))) = data;
+				fill += 16;
+			}
+			req = active && (fill - lend) <= RING - 16;
+			if (req) data = *reinterpret_cast<const u32x4 *>(W.prep + fill);
+			wave_fence();
+			// ---- kRound lookups ----
+			for (uint32_t it = 0; it < kRound; it++) {
+				bool done = false;
+				if (active) {
+					const uint32_t c = ring[cp & (RING - 1)];
+					const uint32_t t = nb + c;
+					const uint32_t x = l_lt[t] ^ c; // 0x80: hit on a token end, 0: hit, else miss
+					const uint32_t b = l_base[t];
+					const uint32_t cp1 = cp + 1;
+					const bool term = x == 0x80u;
+					lend = term ? cp1 : lend;
+					lslot = term ? t : lslot;
+					nb = (x & 0x7Fu) == 0 ? b : 0u;
+					const bool cont = nb != 0;
+					cp = cont ? cp1 : lend;
+					done = !cont;
+				}
+				log.put(done, lslot);
+				if (done) {
+					nb = T.root_base;
+					active = cp < end;
+				}
+				if (log.cur > kLogHigh) log.flush(Qd, lane);
+				act = __builtin_amdgcn_ballot_w64(active);
+				if (act == 0) break;
+			}
+		}
+		if (has_range) W.exit_a[item] = cp - end; // overshoot of the range's last token (cp is its end)
+	}
+	log.finish(Qd, lane);
+}
+
+// ---- range entries: fix-up ------------------------------------------------------------------
+// The protocol of kernels_generic.hip's fix-up (fixup_parallel_kernel / fixup_ordered_kernel), on
+// the prepared corpus and the stream image read from global memory.  Range g counted the chain
+// that starts at g * R + entry[g]; the true chain enters it at g * R + exit[g - 1].  Two greedy
+// chains over the same bytes coincide from the first position they share, so the repair walks
+// whichever chain is behind -- the true one counted +1, the counted one -1 -- until they meet or
+// both have left the range; a repair that never met changes the range's exit, and the ordered
+// kernel then redoes the ranges after it one by one.  entry[] is left holding the true entries.
+struct FixDev {
+	StreamTrieDev T;
+	const uint32_t *slot_id;
+	const uint8_t *prep;
+	uint32_t prep_total, range_bytes, nranges;
+	uint32_t *entry, *exit_a, *exit_b;
+	uint32_t *changed; // set when some repair moved an exit
+	unsigned long long *out;
+	uint32_t total_index;
+};
+
+// one token of the chain at pos: its length and the slot it ends on (the root row is dense and
+// all token ends, so len >= 1; separators stop every walk)
+__device__ __forceinline__ void walk_token_image(const FixDev &F, uint32_t pos, uint32_t &len, uint32_t &slot) {
+	uint32_t nb = F.T.root_base, d = 0;
+	len = 1;
+	slot = 0;
+	while (nb != 0) {
+		const uint32_t c = F.prep[pos + d];
+		const uint32_t t = nb + c;
+		const uint32_t x = F.T.lt[t] ^ c;
+		if ((x & 0x7Fu) != 0) break;
+		d++;
+		if (x == 0x80u) len = d, slot = t;
+		nb = F.T.base[t];
+	}
+}
+
+__device__ __forceinline__ void count_slot(const FixDev &F, uint32_t slot, bool add) {
+	const uint32_t id = F.slot_id[slot];
+	if (id == 0xFFFFFFFFu) return; // separator
+	const unsigned long long v = add ? 1ull : ~0ull;
+	atomicAdd(&F.out[id], v);
+	atomicAdd(&F.out[F.total_index], v);
+}
+
+// true when the chains met (exit unchanged); *pa_out = where the true chain left the range
+__device__ bool dual_walk_image(const FixDev &F, uint32_t end, uint32_t pa, uint32_t pb, uint32_t *pa_out) {
+	while (pa != pb && (pa < end || pb < end)) {
+		uint32_t len, slot;
+		if (pa < pb) {
+			walk_token_image(F, pa, len, slot);
+			count_slot(F, slot, true);
+			pa += len;
+		} else {
+			walk_token_image(F, pb, len, slot);
+			count_slot(F, slot, false);
+			pb += len;
+		}
+	}
+	*pa_out = pa;
+	return pa == pb;
+}
+
+__global__ void __launch_bounds__(256) fixup_parallel_stream_kernel(FixDev F) {
+	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < F.nranges; g += gridDim.x * blockDim.x) {
+		uint32_t ex = F.exit_a[g];
+		if (g > 0) {
+			const uint32_t want = F.exit_a[g - 1];
+			const uint32_t have = F.entry[g];
+			if (want != have) {
+				const uint32_t begin = g * F.range_bytes;
+				const uint32_t end = begin + F.range_bytes < F.prep_total ? begin + F.range_bytes : F.prep_total;
+				uint32_t pa;
+				if (!dual_walk_image(F, end, begin + want, begin + have, &pa)) {
+					ex = pa - end;
+					F.changed[0] = 1u;
+				}
+				F.entry[g] = want;
+			}
+		}
+		F.exit_b[g] = ex;
+	}
+}
+
+// ONE block; every thread reaches every barrier.  Does nothing unless a repair moved an exit.
+__global__ void __launch_bounds__(1024) fixup_ordered_stream_kernel(FixDev F) {
+	__shared__ uint32_t s_first;
+	if (F.changed[0] == 0) return; // uniform: written by the kernel before this one
+	for (uint32_t base = 1; base < F.nranges; base += blockDim.x) {
+		for (;;) {
+			const uint32_t g = base + threadIdx.x;
+			const bool need = g < F.nranges && F.exit_b[g - 1] != F.entry[g];
+			if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
+			__syncthreads();
+			if (need) atomicMin(&s_first, g);
+			__syncthreads();
+			const uint32_t first = s_first;
+			if (first == 0xFFFFFFFFu) break;
+			if (g == first) {
+				const uint32_t want = F.exit_b[g - 1];
+				const uint32_t have = F.entry[g];
+				const uint32_t begin = g * F.range_bytes;
+				const uint32_t end = begin + F.range_bytes < F.prep_total ? begin + F.range_bytes : F.prep_total;
+				uint32_t pa;
+				if (!dual_walk_image(F, end, begin + want, begin + have, &pa)) F.exit_b[g] = pa - end;
+				F.entry[g] = want;
+				__threadfence();
+			}
+			__syncthreads();
+		}
+		__syncthreads();
+	}
+}
+
+// ---- token stream (slot indices) -> slab rows ----------------------------------------------
+// grid = (slab_blocks, slot ranges).  As hist_kernel (kernels_tile.hip), for u16 slot entries
+// (0xFFFF = null, no sign bit: a whole pass either adds or, with flip, subtracts).
+__global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t nslots, uint32_t range_slots,
+                                                          uint32_t *slab, uint32_t flip) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char hist_smem[];
+	uint32_t *bins = reinterpret_cast<uint32_t *>(hist_smem);
+	__shared__ int s_total;
+	const uint32_t lo = blockIdx.y * range_slots;
+	const uint32_t hi = lo + range_slots < nslots ? lo + range_slots : nslots;
+	const uint32_t width = hi - lo;
+	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) bins[i] = 0;
+	if (threadIdx.x == 0) s_total = 0;
+	__syncthreads();
+	uint32_t batches = Qd.cursor[0];
+	if (batches > Qd.capacity_batches) batches = Qd.capacity_batches;
+	constexpr uint32_t vecs_per_block = kLogEntries * 2 / 16; // 64: one 1 KiB row per block
+	constexpr int kRowsInFlight = 8;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t n_waves = gridDim.x * (blockDim.x / 64);
+	const uint32_t wave_id = uni32(blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6));
+	const uint4 *vec = reinterpret_cast<const uint4 *>(Qd.blocks);
+	const uint32_t sgn = flip ? 0xFFFFFFFFu : 1u;
+	uint32_t seen = 0;
+	for (uint32_t bt = wave_id; bt < batches; bt += n_waves) {
+		uint32_t live = Qd.fill[bt];
+		if (live > kStreamBatch) live = kStreamBatch;
+		const uint32_t live_rows = uni32(live);
+		const uint4 *rows = vec + (uint64_t)bt * kStreamBatch * vecs_per_block + lane;
+		for (uint32_t r0 = 0; r0 < live_rows; r0 += kRowsInFlight) {
+			uint4 v[kRowsInFlight];
+#pragma unroll
+			for (int u = 0; u < kRowsInFlight; u++) {
+				v[u] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+				if (r0 + u < live_rows) v[u] = rows[(size_t)(r0 + u) * 64];
+			}
+#pragma unroll
+			for (int u = 0; u < kRowsInFlight; u++) {
+				const uint32_t wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+				for (int k = 0; k < 4; k++) {
+					if (wds[k] == 0xFFFFFFFFu) continue;
+#pragma unroll
+					for (int h = 0; h < 2; h++) {
+						const uint32_t e = (wds[k] >> (16 * h)) & 0xFFFFu;
+						if (e == 0xFFFFu) continue;
+						seen++;
+						if (e >= lo && e < hi) atomicAdd(&bins[e - lo], sgn);
+					}
+				}
+			}
+		}
+	}
+	if (blockIdx.y == 0) {
+		int total = flip ? -(int)seen : (int)seen;
+		for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+		if ((threadIdx.x & 63) == 0 && total != 0) atomicAdd(&s_total, total);
+	}
+	__syncthreads();
+	uint32_t *row = slab + (size_t)blockIdx.x * (nslots + 1);
+	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) row[lo + i] = bins[i];
+	if (blockIdx.y == 0 && threadIdx.x == 0) row[nslots] = (uint32_t)s_total;
+}
+
+// Slab rows (int32 partials per slot, column nslots = entries seen) -> out: counts[slot_id[s]] +=
+// column sums; entries on slots nobody counts (document separators) leave the token total again
+// (main.cpp:41 counts the ids Tokenize returned, not the separators this layout adds).
+constexpr uint32_t kMapReduceGroups = 16;
+__global__ void __launch_bounds__(256) slab_reduce_map_kernel(const uint32_t *slab, uint32_t rows, uint32_t nslots,
+                                                              const uint32_t *slot_id, unsigned long long *out,
+                                                              uint32_t total_index) {
+	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+	if (s > nslots) return;
+	long long sum = 0;
+	for (uint32_t r = blockIdx.y; r < rows; r += kMapReduceGroups) sum += (long long)(int32_t)slab[(size_t)r * (nslots + 1) + s];
+	if (sum == 0) return;
+	if (s == nslots) {
+		atomicAdd(&out[total_index], (unsigned long long)sum);
+		return;
+	}
+	const uint32_t id = slot_id[s];
+	if (id == 0xFFFFFFFFu) atomicAdd(&out[total_index], (unsigned long long)(-sum));
+	else atomicAdd(&out[id], (unsigned long long)sum);
+}
+
+} // namespace
+
+// ---- host side -----------------------------------------------------------------------------
+
+void launch_prep_corpus(const CorpusDev &C, const ByteCodes &M, uint8_t *prep, uint64_t prep_total, uint32_t *flags,
+                        hipStream_t stream) {
+	if (prep_total == 0 || C.D == 0) return;
+	const uint64_t nvec = (prep_total + 15) / 16;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>((nvec + 255) / 256, 1u << 16);
+	hipLaunchKernelGGL(prep_corpus_kernel, dim3(blocks), dim3(256), 0, stream, C, M, prep, prep_total, flags);
+}
+
+bool plan_stream_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan) {
+	uint32_t ring = 0;
+	if (max_len + 2 * kRound + 14 <= 64) ring = 64;
+	else if (max_len + 2 * kRound + 14 <= 128) ring = 128;
+	else return false;
+	const uint32_t label_bytes = (nslots + 15) & ~15u;
+	const uint32_t info_bytes = (nslots * 2 + 15) & ~15u;
+	const uint32_t wave_bytes = 64 * ring + kLogEntries * 2;
+	const uint32_t lds_total = 160 * 1024 - 64; // hist_slots_kernel's static word and slack
+	if (label_bytes + info_bytes + wave_bytes > lds_total) return false;
+	uint32_t waves = (lds_total - label_bytes - info_bytes) / wave_bytes;
+	if (waves > 16) waves = 16;
+	if (const char *s = getenv("TOKSCORE_WAVES")) waves = std::min<uint32_t>(waves, (uint32_t)std::max(1, atoi(s)));
+	if (waves < 4 && !getenv("TOKSCORE_WAVES")) return false; // too little of the CU left to hide the LDS latency: tile path
+	plan->ring = ring;
+	plan->waves_per_block = waves;
+	plan->blocks = num_cus;
+	plan->lds_bytes = label_bytes + info_bytes + waves * wave_bytes;
+	return true;
+}
+
+void launch_scan_stream(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
+                        hipStream_t stream) {
+	if (plan.ring == 64) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_stream_kernel<64>),
+		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+		hipLaunchKernelGGL(scan_stream_kernel<64>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream,
+		                   T, W, Q);
+	} else {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_stream_kernel<128>),
+		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+		hipLaunchKernelGGL(scan_stream_kernel<128>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream,
+		                   T, W, Q);
+	}
+}
+
+void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
+                            uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip) {
+	constexpr uint32_t kMaxRange = 40000;
+	const uint32_t ranges = (nslots + kMaxRange - 1) / kMaxRange;
+	const uint32_t range = (nslots + ranges - 1) / ranges;
+	const uint32_t lds = range * 4;
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_slots_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                          (int)lds);
+	hipLaunchKernelGGL(hist_slots_kernel, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, nslots, range, slab,
+	                   flip ? 1u : 0u);
+	hipLaunchKernelGGL(slab_reduce_map_kernel, dim3((nslots + 1 + 255) / 256, kMapReduceGroups), dim3(256), 0, stream, slab,
+	                   slab_blocks, nslots, slot_id, out, total_index);
+}
+
+void launch_fixup_stream(const StreamTrieDev &T, const uint32_t *slot_id, const StreamWork &W, uint32_t *exit_b,
+                         uint32_t *changed, unsigned long long *out, uint32_t total_index, hipStream_t stream) {
+	if (W.nranges < 2) return;
+	FixDev F{T, slot_id, W.prep, W.prep_total, W.range_bytes, W.nranges, W.entry, W.exit_a, exit_b, changed, out, total_index};
+	const uint32_t blocks = std::min<uint32_t>((W.nranges + 255) / 256, 8192);
+	hipLaunchKernelGGL(fixup_parallel_stream_kernel, dim3(blocks), dim3(256), 0, stream, F);
+	hipLaunchKernelGGL(fixup_ordered_stream_kernel, dim3(1), dim3(1024), 0, stream, F);
+}
+
+uint64_t stream_scan_capacity_batches(uint64_t prep_total, uint32_t waves_total) {
+	// one entry per prepared byte at most; a flushed block holds more than kLogHigh entries, every
+	// wave ends with one partial block and one partial batch
+	const uint64_t blocks = prep_total / (kLogHigh + 1) + waves_total + 1;
+	return (blocks + kStreamBatch - 1) / kStreamBatch + waves_total + 16;
+}
+
+} // namespace tokscore

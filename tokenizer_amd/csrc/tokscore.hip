@@ -121,6 +121,29 @@ struct tokscore_ctx {
 	uint32_t *d_slab = nullptr;
 	uint32_t slab_blocks = 0;
 
+	// stream scan (kernels_stream.hip): trie image, prepared corpus, stream boundaries
+	StreamImage simg;
+	bool simg_valid = false;         // host image matches the trie + hotness
+	uint8_t *d_slt = nullptr;
+	uint16_t *d_sbase = nullptr;
+	uint32_t *d_slot_id = nullptr;
+	std::vector<int64_t> pending_s;  // stream-image slots of the pending toggles
+	uint64_t d_simg_cap = 0;
+	uint8_t *d_prep = nullptr;       // codes of the lower-cased documents, code 0 after each (per corpus + vocabulary)
+	uint64_t prep_total = 0;         // total + D
+	bool prep_ok = false;            // built, and no document holds a NUL byte
+	StreamScanPlan splan = {};
+	uint32_t *d_pbeg = nullptr;      // [nstreams + 1] prepared offsets
+	uint32_t *d_chunk_first = nullptr; // [nchunks + 1] first stream of every chunk
+	bool chunks_synced = false;      // every chunk begins at a kept cut (what an incremental re-score needs)
+	uint32_t nstreams = 0;
+	uint32_t streams_per_chunk = 1;
+	uint32_t range_bytes = 0;        // full evaluation: equal ranges of the prepared corpus, one per lane
+	uint32_t nranges = 0;
+	uint32_t *d_range_state = nullptr; // entry | exit_a | exit_b, nranges words each
+	uint8_t *h_patch_lt = nullptr;    // pinned, beside h_patch
+	uint32_t *h_patch_id = nullptr;
+
 	// outputs
 	unsigned long long *d_out = nullptr;
 	uint64_t d_out_cap = 0;
@@ -156,9 +179,52 @@ void free_corpus(tokscore_ctx *c) {
 	}
 	c->d_bytes = nullptr;
 	c->d_off = nullptr;
+	if (c->d_prep) (void)hipFree(c->d_prep);
+	c->d_prep = nullptr;
+	c->prep_ok = false;
+	c->prep_total = 0;
 	c->own_corpus = false;
 	c->corpus_set = false;
 	c->plan_valid = false;
+}
+
+// The stream scan's copy of the corpus (kernels_stream.hip: prep_corpus_kernel), built once per
+// corpus + vocabulary (with the plan): codes of the lower-cased bytes, code 0 after every document.
+// prep_ok stays false when a document holds a NUL byte or the copy would not fit 32-bit offsets:
+// the tile scan is used then.
+int build_prepared(tokscore_ctx *c) {
+	c->prep_ok = false;
+	if (c->d_prep) (void)hipFree(c->d_prep);
+	c->d_prep = nullptr;
+	c->prep_total = c->total + c->D;
+	if (c->D == 0 || c->prep_total + kCorpusPad >= 0xFFFF0000ull || env_u64("TOKSCORE_NOPREP", 0)) return TOKSCORE_OK;
+	uint32_t *d_flags = nullptr;
+	uint32_t flags = 1;
+	hipError_t e = hipMalloc((void **)&c->d_prep, c->prep_total + kCorpusPad);
+	if (e == hipSuccess) e = hipMalloc((void **)&d_flags, sizeof(uint32_t));
+	if (e == hipSuccess) e = hipMemsetAsync(c->d_prep + (c->prep_total & ~15ull), 0, kCorpusPad + (c->prep_total & 15), c->stream);
+	if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t), c->stream);
+	if (e == hipSuccess) {
+		CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+		ByteCodes M;
+		memcpy(M.code, c->simg.code, 256);
+		launch_prep_corpus(C, M, c->d_prep, c->prep_total, d_flags, c->stream);
+		e = hipMemcpyAsync(&flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (d_flags) (void)hipFree(d_flags);
+	if (e != hipSuccess) {
+		(void)hipGetLastError();
+		if (c->d_prep) (void)hipFree(c->d_prep);
+		c->d_prep = nullptr;
+		return TOKSCORE_OK; // not fatal: the tile scan needs no prepared copy
+	}
+	c->prep_ok = flags == 0;
+	if (!c->prep_ok) {
+		(void)hipFree(c->d_prep);
+		c->d_prep = nullptr;
+	}
+	return TOKSCORE_OK;
 }
 
 void free_plan(tokscore_ctx *c) {
@@ -181,6 +247,12 @@ void free_plan(tokscore_ctx *c) {
 	c->d_index = nullptr;
 	c->index_state = 0;
 	if (c->d_slab) (void)hipFree(c->d_slab);
+	if (c->d_pbeg) (void)hipFree(c->d_pbeg);
+	c->d_pbeg = nullptr;
+	if (c->d_chunk_first) (void)hipFree(c->d_chunk_first);
+	c->d_chunk_first = nullptr;
+	if (c->d_range_state) (void)hipFree(c->d_range_state);
+	c->d_range_state = nullptr;
 	c->d_chunk_begin = nullptr;
 	c->d_chunk_state = nullptr;
 	c->d_stream = nullptr;
@@ -224,6 +296,32 @@ TrieDev trie_dev(const tokscore_ctx *c) {
 	return T;
 }
 
+StreamTrieDev stream_trie_dev(const tokscore_ctx *c) {
+	StreamTrieDev T;
+	T.lt = c->d_slt;
+	T.base = c->d_sbase;
+	T.nslots = (uint32_t)c->simg.lt.size();
+	T.root_base = c->simg.root_base;
+	return T;
+}
+
+StreamWork stream_work(const tokscore_ctx *c, bool selected) {
+	StreamWork W;
+	W.prep = c->d_prep;
+	W.pbeg = c->d_pbeg;
+	W.nstreams = c->nstreams;
+	W.prep_total = (uint32_t)c->prep_total;
+	W.range_bytes = c->range_bytes;
+	W.nranges = c->nranges;
+	W.entry = c->d_range_state;
+	W.exit_a = c->d_range_state + c->nranges;
+	W.sel_list = selected ? c->d_sel_list : nullptr;
+	W.sel_count = selected ? c->d_sel_list + c->nchunks : nullptr;
+	W.chunk_first = c->d_chunk_first;
+	W.streams_per_chunk = 2 * c->streams_per_chunk; // a chunk's first cut may have moved up to one chunk forward
+	return W;
+}
+
 int ensure_trie(tokscore_ctx *c) {
 	if (!c->vocab_set) return fail(c, TOKSCORE_E_STATE, "vocabulary not set");
 	if (!c->packed_valid || (!c->sample_used && !c->sample.empty())) {
@@ -236,8 +334,30 @@ int ensure_trie(tokscore_ctx *c) {
 		c->packed_valid = true;
 		c->device_trie_valid = false;
 		c->plan_valid = false;
+		c->simg_valid = c->trie.PackStream(&c->simg);
 	}
 	if (c->hostonly) return TOKSCORE_OK;
+	if (!c->device_trie_valid && c->simg_valid) {
+		// the stream scan's image: label[] (padded to 16 bytes), info[], slot_id[]
+		const uint64_t n = c->simg.lt.size();
+		const uint64_t npad = (n + 15) & ~15ull;
+		if (npad > c->d_simg_cap) {
+			if (c->d_slt) (void)hipFree(c->d_slt);
+			if (c->d_sbase) (void)hipFree(c->d_sbase);
+			if (c->d_slot_id) (void)hipFree(c->d_slot_id);
+			c->d_slt = nullptr, c->d_sbase = nullptr, c->d_slot_id = nullptr;
+			c->d_simg_cap = 0;
+			HIP_TRY(c, hipMalloc((void **)&c->d_slt, npad));
+			HIP_TRY(c, hipMalloc((void **)&c->d_sbase, npad * sizeof(uint16_t)));
+			HIP_TRY(c, hipMalloc((void **)&c->d_slot_id, npad * sizeof(uint32_t)));
+			c->d_simg_cap = npad;
+		}
+		HIP_TRY(c, hipMemsetAsync(c->d_slt, 0, npad, c->stream));
+		HIP_TRY(c, hipMemsetAsync(c->d_sbase, 0, npad * sizeof(uint16_t), c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_slt, c->simg.lt.data(), n, hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_sbase, c->simg.base.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice, c->stream));
+		HIP_TRY(c, hipMemcpyAsync(c->d_slot_id, c->simg.slot_id.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+	}
 	if (!c->device_trie_valid) {
 		const uint64_t n = c->packed.slots.size();
 		if (n > c->d_slots_cap) {
@@ -251,6 +371,7 @@ int ensure_trie(tokscore_ctx *c) {
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		c->device_trie_valid = true;
 		c->pending.clear();
+		c->pending_s.clear();
 		c->state_valid = false;
 	}
 	if (!c->d_vocab_valid) {
@@ -280,9 +401,153 @@ int apply_pending(tokscore_ctx *c, hipStream_t s) {
 			}
 			HIP_TRY(c, hipMemcpyAsync(c->d_slots + pd.second, src, sizeof(uint64_t), hipMemcpyHostToDevice, s));
 		}
+		// the same toggles in the stream image (kept up to date on the host by tokscore_toggle):
+		// token-end bit and the id the slot counts for
+		const bool staged_s = staged && c->pending_s.size() <= kMaxPatch;
+		k = 0;
+		for (const int64_t t : c->pending_s) {
+			if (!c->simg_valid || !c->d_slt) break;
+			const uint8_t *src_lt = &c->simg.lt[t];
+			const uint32_t *src_id = &c->simg.slot_id[t];
+			if (staged_s) {
+				c->h_patch_lt[k] = *src_lt, c->h_patch_id[k] = *src_id;
+				src_lt = &c->h_patch_lt[k], src_id = &c->h_patch_id[k];
+				k++;
+			}
+			HIP_TRY(c, hipMemcpyAsync(c->d_slt + t, src_lt, sizeof(uint8_t), hipMemcpyHostToDevice, s));
+			HIP_TRY(c, hipMemcpyAsync(c->d_slot_id + t, src_id, sizeof(uint32_t), hipMemcpyHostToDevice, s));
+		}
 		if (staged) c->patch_in_flight = true; // until the next wait on c->stream (fetch_out)
 	}
 	c->pending.clear();
+	c->pending_s.clear();
+	return TOKSCORE_OK;
+}
+
+// Boundaries (corpus offsets, b[0] = 0 .. b[n] = total) moved forward to guaranteed token starts
+// (kernels_generic.hip: snap_chunks_kernel); syn[j] = 0 where none was found within `window`.
+int snap_boundaries(tokscore_ctx *c, std::vector<uint64_t> &b, uint32_t window, std::vector<uint32_t> &syn) {
+	const size_t nb = b.size();
+	syn.assign(nb, 1);
+	if (nb < 3) return TOKSCORE_OK;
+	uint64_t *d_old = nullptr, *d_new = nullptr;
+	uint32_t *d_syn = nullptr;
+	hipError_t e = hipMalloc((void **)&d_old, nb * sizeof(uint64_t));
+	if (e == hipSuccess) e = hipMalloc((void **)&d_new, nb * sizeof(uint64_t));
+	if (e == hipSuccess) e = hipMalloc((void **)&d_syn, nb * sizeof(uint32_t));
+	// (both copies from the host: a device-to-device hipMemcpy is not ordered against c->stream,
+	// and the kernel below must not be overtaken by it)
+	if (e == hipSuccess) e = hipMemcpy(d_old, b.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d_new, b.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+		launch_snap_chunks(trie_dev(c), C, d_old, d_new, d_syn, (uint32_t)(nb - 1), (uint32_t)c->packed.max_len, window, c->stream);
+		e = hipStreamSynchronize(c->stream);
+	}
+	if (e == hipSuccess) e = hipMemcpy(b.data(), d_new, nb * sizeof(uint64_t), hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(syn.data() + 1, d_syn + 1, (nb - 2) * sizeof(uint32_t), hipMemcpyDeviceToHost);
+	if (d_old) (void)hipFree(d_old);
+	if (d_new) (void)hipFree(d_new);
+	if (d_syn) (void)hipFree(d_syn);
+	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("snap_chunks: ") + hipGetErrorString(e));
+	return TOKSCORE_OK;
+}
+
+// Plan of the stream scan (kernels_stream.hip).  Streams: the corpus cut every stream_bytes, every
+// cut moved forward to a guaranteed token start; a cut that could not be moved to one is dropped
+// (its stream joins the one before).  Chunks, the unit the incremental re-score selects, are
+// streams_per_chunk consecutive streams.  *ok = false: not for this vocabulary / corpus, nothing kept.
+int plan_stream(tokscore_ctx *c, bool *ok) {
+	*ok = false;
+	if (!c->simg_valid || c->total == 0) return TOKSCORE_OK;
+	StreamScanPlan sp;
+	if (!plan_stream_scan((uint32_t)c->simg.lt.size(), c->packed.max_len, (uint32_t)c->num_cus, &sp)) return TOKSCORE_OK;
+	int st = build_prepared(c);
+	if (st || !c->prep_ok) return st;
+	uint64_t sbytes = env_u64("TOKSCORE_STREAM", 256);
+	sbytes = std::max<uint64_t>(sbytes, std::max<uint64_t>(64, 4 * c->packed.max_len));
+	const uint64_t spc = std::max<uint64_t>(1, std::min<uint64_t>(64, env_u64("TOKSCORE_SPC", 16)));
+	std::vector<uint64_t> sb; // stream boundaries, corpus offsets
+	{
+		std::vector<uint64_t> keep;
+		keep.swap(c->h_chunk_begin);
+		build_chunks(c, sbytes, true);
+		sb.swap(c->h_chunk_begin);
+		c->h_chunk_begin.swap(keep);
+	}
+	std::vector<uint32_t> syn;
+	const uint32_t window = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(sbytes - 1, 8192));
+	st = snap_boundaries(c, sb, window, syn);
+	if (st) return st;
+	const size_t ns = sb.size() - 1;
+	size_t unsynced = 0;
+	for (size_t j = 1; j < ns; j++) unsynced += syn[j] ? 0 : 1;
+	// prepared offsets: position p of document d (off[d] <= p < off[d+1]) sits at p + d; the corpus end at total + D
+	std::vector<uint32_t> pb(ns + 1);
+	{
+		size_t d = 0; // largest d with off[d] <= sb[j]
+		for (size_t j = 0; j <= ns; j++) {
+			while (d < c->D && c->h_off[d + 1] <= sb[j]) d++;
+			pb[j] = (uint32_t)(sb[j] + d);
+		}
+		pb[ns] = (uint32_t)c->prep_total;
+		for (size_t j = ns; j-- > 1;)
+			if (!syn[j]) pb[j] = pb[j + 1]; // dropped cut: the stream before it runs on to the next kept one
+	}
+	// chunks: from every spc-th stream boundary, or the first kept cut after it (a chunk must begin
+	// where some lane begins a stream, or re-scanning it alone would not be exact)
+	c->h_chunk_begin.clear();
+	std::vector<uint32_t> cfirst;
+	c->chunks_synced = true;
+	for (size_t j = 0; j < ns; j += spc) {
+		size_t k = j;
+		while (k < ns && k < j + spc && !syn[k]) k++;
+		if (k == ns || k == j + spc) { // no kept cut in this chunk's range: no incremental re-scores on this plan
+			c->chunks_synced = false;
+			k = j;
+		}
+		cfirst.push_back((uint32_t)k);
+		c->h_chunk_begin.push_back(sb[k]);
+	}
+	cfirst.push_back((uint32_t)ns);
+	c->h_chunk_begin.push_back(c->total);
+	c->nchunks = (uint32_t)(c->h_chunk_begin.size() - 1);
+	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_first, cfirst.size() * sizeof(uint32_t)));
+	HIP_TRY(c, hipMemcpy(c->d_chunk_first, cfirst.data(), cfirst.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+	c->chunk_bytes = sbytes * spc;
+	c->uniform_chunks = true;
+	c->unsynced = (uint32_t)unsynced;
+	c->nstreams = (uint32_t)ns;
+	c->streams_per_chunk = (uint32_t)spc;
+	c->splan = sp;
+	// full evaluation: as many equal ranges as the grid has lanes (none shorter than four tokens)
+	const uint64_t lanes = (uint64_t)sp.blocks * sp.waves_per_block * 64;
+	uint64_t rb = (c->prep_total + lanes - 1) / lanes;
+	rb = std::max<uint64_t>(rb, std::max<uint64_t>(64, 4 * c->packed.max_len));
+	rb = std::max<uint64_t>(rb, env_u64("TOKSCORE_RANGE", 0));
+	c->range_bytes = (uint32_t)rb;
+	c->nranges = (uint32_t)((c->prep_total + rb - 1) / rb);
+	HIP_TRY(c, hipMalloc((void **)&c->d_range_state, (size_t)3 * c->nranges * sizeof(uint32_t)));
+	HIP_TRY(c, hipMemset(c->d_range_state, 0, (size_t)3 * c->nranges * sizeof(uint32_t)));
+	HIP_TRY(c, hipMalloc((void **)&c->d_pbeg, (ns + 1) * sizeof(uint32_t)));
+	HIP_TRY(c, hipMemcpy(c->d_pbeg, pb.data(), (ns + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_begin, c->h_chunk_begin.size() * sizeof(uint64_t)));
+	HIP_TRY(c, hipMemcpy(c->d_chunk_begin, c->h_chunk_begin.data(), c->h_chunk_begin.size() * sizeof(uint64_t),
+	                     hipMemcpyHostToDevice));
+	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, kCursorWords * sizeof(uint32_t)));
+	HIP_TRY(c, hipMalloc((void **)&c->d_sel, ((size_t)(c->nchunks + 31) / 32 + 1) * sizeof(uint32_t)));
+	HIP_TRY(c, hipMalloc((void **)&c->d_sel_list, ((size_t)c->nchunks + 1) * sizeof(uint32_t)));
+	// token stream: at most one entry per prepared byte (every token and every separator is at
+	// least one byte), so this capacity cannot be exceeded whatever the input
+	const uint64_t batches = stream_scan_capacity_batches(c->prep_total, sp.blocks * sp.waves_per_block);
+	if (batches > 0x7FFFFFF0ull) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one token stream");
+	c->stream_cap_batches = (uint32_t)batches;
+	HIP_TRY(c, hipMalloc(&c->d_stream, batches * kStreamBatch * 1024));
+	HIP_TRY(c, hipMalloc((void **)&c->d_fill, batches * sizeof(uint32_t)));
+	c->slab_blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, c->total / (256 * 1024)));
+	c->slab_blocks = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, env_u64("TOKSCORE_SLAB_BLOCKS", c->slab_blocks)));
+	HIP_TRY(c, hipMalloc((void **)&c->d_slab, (size_t)c->slab_blocks * (c->simg.lt.size() + 1) * sizeof(uint32_t)));
+	*ok = true;
 	return TOKSCORE_OK;
 }
 
@@ -290,6 +555,18 @@ int ensure_plan(tokscore_ctx *c) {
 	if (c->plan_valid) return TOKSCORE_OK;
 	free_plan(c);
 	const char *force = getenv("TOKSCORE_SCAN");
+	if (!c->force_generic && (!force || !strcmp(force, "stream"))) {
+		bool ok = false;
+		int st = plan_stream(c, &ok);
+		if (st) return st;
+		if (ok) {
+			c->scan_path = 2;
+			c->tile = TileScanPlan{};
+			c->plan_valid = true;
+			return TOKSCORE_OK;
+		}
+		free_plan(c);
+	}
 	TrieDev T = trie_dev(c);
 	bool tile_ok = plan_tile_scan(T, c->packed.max_len, (uint32_t)c->V, (uint32_t)c->num_cus, &c->tile);
 	if (force && !strcmp(force, "generic")) tile_ok = false;
@@ -328,7 +605,7 @@ int ensure_plan(tokscore_ctx *c) {
 		HIP_TRY(c, hipMalloc((void **)&d_new, nb * sizeof(uint64_t)));
 		hipError_t e = hipMalloc((void **)&d_syn, nb * sizeof(uint32_t));
 		std::vector<uint32_t> syn(nb, 1);
-		if (e == hipSuccess) e = hipMemcpy(d_new, c->d_chunk_begin, nb * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+		if (e == hipSuccess) e = hipMemcpy(d_new, c->h_chunk_begin.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice);
 		if (e == hipSuccess) {
 			CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
 			const uint32_t window = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(c->chunk_bytes - 1, 8192));
@@ -337,7 +614,7 @@ int ensure_plan(tokscore_ctx *c) {
 		}
 		if (e == hipSuccess) e = hipMemcpy(c->h_chunk_begin.data(), d_new, nb * sizeof(uint64_t), hipMemcpyDeviceToHost);
 		if (e == hipSuccess) e = hipMemcpy(syn.data() + 1, d_syn + 1, (c->nchunks - 1) * sizeof(uint32_t), hipMemcpyDeviceToHost);
-		if (e == hipSuccess) e = hipMemcpy(c->d_chunk_begin, d_new, nb * sizeof(uint64_t), hipMemcpyDeviceToDevice);
+		if (e == hipSuccess) e = hipMemcpy(c->d_chunk_begin, c->h_chunk_begin.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice);
 		(void)hipFree(d_new);
 		if (d_syn) (void)hipFree(d_syn);
 		if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("snap_chunks: ") + hipGetErrorString(e));
@@ -389,7 +666,11 @@ int ensure_out(tokscore_ctx *c) {
 		HIP_TRY(c, hipHostMalloc((void **)&c->h_out, (n + 1) * sizeof(uint64_t), hipHostMallocDefault));
 		c->d_out_cap = n;
 	}
-	if (!c->h_patch) HIP_TRY(c, hipHostMalloc((void **)&c->h_patch, kMaxPatch * sizeof(uint64_t), hipHostMallocDefault));
+	if (!c->h_patch) {
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_patch, kMaxPatch * 16, hipHostMallocDefault));
+		c->h_patch_id = reinterpret_cast<uint32_t *>(c->h_patch + kMaxPatch);
+		c->h_patch_lt = reinterpret_cast<uint8_t *>(c->h_patch_id + kMaxPatch);
+	}
 	return TOKSCORE_OK;
 }
 
@@ -398,7 +679,7 @@ int fetch_out(tokscore_ctx *c, hipStream_t s) {
 	const uint64_t n = c->V + 5;
 	c->h_out[n] = 0;
 	HIP_TRY(c, hipMemcpyAsync(c->h_out, c->d_out, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-	if (c->scan_path == 1 && c->d_cursor)
+	if (c->scan_path >= 1 && c->d_cursor)
 		HIP_TRY(c, hipMemcpyAsync(c->h_out + n, c->d_cursor, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	HIP_TRY(c, hipStreamSynchronize(s));
 	c->patch_in_flight = false;
@@ -420,7 +701,7 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
 	             c->d_chunk_state + 2 * (size_t)(c->nchunks + 1), c->nchunks};
 	// fix-up kernels only when some chunk starts at a speculated position
-	const bool repair = c->unsynced != 0;
+	const bool repair = c->unsynced != 0 && c->scan_path != 2; // (the stream scan drops cuts it could not snap)
 	// events: scan start, scan end, [fix-up forked,] end.  Each record holds the stream for about
 	// 5 us, so the evaluation start shares the scan-start event (prepare_kernel, 4 us, is outside)
 	// and without fix-up kernels the "fix-up" interval is empty.
@@ -436,7 +717,19 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		c->ev = view;
 	}
 	auto mark = [&](int k) -> hipError_t { return ev ? hipEventRecord(ev[k], s) : hipSuccess; };
-	if (c->scan_path == 1) {
+	if (c->scan_path == 2) {
+		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
+		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s);
+		HIP_TRY(c, mark(1));
+		const StreamWork W = stream_work(c, false);
+		launch_scan_stream(stream_trie_dev(c), W, Q, c->splan, s);
+		HIP_TRY(c, mark(2));
+		// ranges whose entry was not the previous range's exit (none while the vocabulary stays as it is)
+		launch_fixup_stream(stream_trie_dev(c), c->d_slot_id, W, c->d_range_state + 2 * (size_t)c->nranges, c->d_cursor + 2, d_out,
+		                    (uint32_t)c->V + 3, s);
+		launch_histogram_slots(Q, (uint32_t)c->simg.lt.size(), c->d_slot_id, d_out, (uint32_t)c->V + 3, c->d_slab,
+		                       c->slab_blocks, s);
+	} else if (c->scan_path == 1) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s);
 		HIP_TRY(c, mark(1));
@@ -515,7 +808,7 @@ void build_index(tokscore_ctx *c) {
 }
 
 int check_overflow(tokscore_ctx *c) { // after fetch_out
-	if (c->scan_path != 1) return TOKSCORE_OK;
+	if (c->scan_path < 1) return TOKSCORE_OK;
 	if (c->h_out[c->V + 5] >> 32) return fail(c, TOKSCORE_E_CAPACITY, "token stream overflow (internal capacity bound violated)");
 	return TOKSCORE_OK;
 }
@@ -600,6 +893,9 @@ void tokscore_destroy(tokscore_ctx *c) {
 		free_corpus(c);
 		if (c->d_slots) (void)hipFree(c->d_slots);
 		if (c->d_vocab_bytes) (void)hipFree(c->d_vocab_bytes);
+		if (c->d_slt) (void)hipFree(c->d_slt);
+		if (c->d_sbase) (void)hipFree(c->d_sbase);
+		if (c->d_slot_id) (void)hipFree(c->d_slot_id);
 		if (c->d_out) (void)hipFree(c->d_out);
 		if (c->h_out) (void)hipHostFree(c->h_out);
 		if (c->h_patch) (void)hipHostFree(c->h_patch);
@@ -624,6 +920,8 @@ int tokscore_set_vocab(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *of
 	c->device_trie_valid = false;
 	c->plan_valid = false;
 	c->pending.clear();
+	c->pending_s.clear();
+	c->simg_valid = false;
 	c->state_valid = false;
 	c->d_vocab_valid = false;
 	if (!c->trie.Build(bytes ? bytes : &kEmpty, off, V, &e)) return fail(c, TOKSCORE_E_VOCAB, e);
@@ -653,6 +951,8 @@ int tokscore_toggle(tokscore_ctx *c, uint64_t token_index, int enable) {
 	}
 	uint64_t entry = 0;
 	const int64_t slot = c->trie.Toggle(token_index, enable != 0, &c->packed, &entry);
+	const int64_t sslot = c->simg_valid ? c->trie.PatchStream(token_index, &c->simg) : -1;
+	if (sslot >= 0 && !c->hostonly && c->device_trie_valid) c->pending_s.push_back(sslot);
 	// The device copy is patched by the next evaluation (apply_pending): an incremental
 	// re-score first takes back what the OLD trie counted in the chunks the token occurs in.
 	if (slot >= 0 && !c->hostonly && c->device_trie_valid) c->pending.emplace_back(token_index, slot);
@@ -782,7 +1082,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
 	(void)hipSetDevice(c->device);
 	const bool eligible = c->state_valid && c->plan_valid && c->packed_valid && c->device_trie_valid && c->d_vocab_valid &&
-	                      c->scan_path == 1 && c->unsynced == 0 && c->uniform_chunks && c->pending.size() <= kMaxPatch &&
+	                      c->scan_path >= 1 && (c->scan_path == 2 ? c->chunks_synced : c->unsynced == 0) && c->uniform_chunks && c->pending.size() <= kMaxPatch &&
 	                      !env_u64("TOKSCORE_NOINCR", 0);
 	if (!eligible) return tokscore_score(c, counts, total_tokens, total_bytes);
 	hipStream_t s = c->stream;
@@ -853,23 +1153,26 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		if (nsel && !listed) launch_compact_sel(c->d_sel, c->nchunks, c->d_sel_list, s);
 		const uint32_t hist_blocks = std::max<uint32_t>(1, std::min<uint32_t>(c->slab_blocks, (nsel + 15) / 16));
 		HIP_TRY(c, mark(1));
-		if (nsel) {
+		// one partial pass: the selected chunks scanned under the device trie as it is now
+		auto partial_pass = [&](bool flip) {
 			launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s);
-			launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s, c->d_sel_list,
-			                 c->d_sel_list + c->nchunks);
-			launch_histogram(Q, c->tile, (uint32_t)c->V, c->d_out, c->d_slab, hist_blocks, s, /*flip=*/true);
-		}
+			if (c->scan_path == 2) {
+				launch_scan_stream(stream_trie_dev(c), stream_work(c, true), Q, c->splan, s);
+				launch_histogram_slots(Q, (uint32_t)c->simg.lt.size(), c->d_slot_id, c->d_out, (uint32_t)c->V + 3, c->d_slab,
+				                       hist_blocks, s, flip);
+			} else {
+				launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s, c->d_sel_list,
+				                 c->d_sel_list + c->nchunks);
+				launch_histogram(Q, c->tile, (uint32_t)c->V, c->d_out, c->d_slab, hist_blocks, s, flip);
+			}
+		};
+		if (nsel) partial_pass(/*flip=*/true);
 		HIP_TRY(c, mark(2));
 		c->state_valid = false; // until the second half is in
 		int st = apply_pending(c, s);
 		if (st) return st;
 		HIP_TRY(c, mark(3));
-		if (nsel) {
-			launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s);
-			launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s, c->d_sel_list,
-			                 c->d_sel_list + c->nchunks);
-			launch_histogram(Q, c->tile, (uint32_t)c->V, c->d_out, c->d_slab, hist_blocks, s, /*flip=*/false);
-		}
+		if (nsel) partial_pass(/*flip=*/false);
 		HIP_TRY(c, mark(4));
 		HIP_TRY(c, hipGetLastError());
 		c->timing_pending = ev != nullptr;
@@ -1070,7 +1373,7 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 	if (c->plan_valid) {
 		info->chunks = c->nchunks;
 		info->scan_path = (uint32_t)c->scan_path;
-		info->trie_lds_slots = c->tile.lds_slots;
+		info->trie_lds_slots = c->scan_path == 2 ? (uint32_t)c->simg.lt.size() : c->tile.lds_slots;
 	}
 	info->rescored_chunks = c->rescored_chunks;
 	return TOKSCORE_OK;

@@ -263,6 +263,182 @@ bool VocabTrie::Pack(PackedTrie *out, std::string *err) {
 	return true;
 }
 
+// lt / slot_id of the slot of `node` (a child of the root when depth 1), reached by `code`
+void VocabTrie::StreamSlotValues(uint32_t node, uint32_t code, uint8_t *lt, uint32_t *slot_id) const {
+	const uint32_t id = ActiveId(node);
+	if (depth_[node] == 1) { // root row: always a token end; no token of its own = UNKNOWN
+		*lt = (uint8_t)(code | 0x80u);
+		*slot_id = id ? id : (uint32_t)(V_ + 2);
+	} else {
+		*lt = (uint8_t)(code | (id ? 0x80u : 0u));
+		*slot_id = id ? id : StreamImage::kSkipSlot;
+	}
+}
+
+bool VocabTrie::PackStream(StreamImage *out) {
+	out->valid = false;
+	const uint32_t N = (uint32_t)first_child_.size();
+	// codes: 0 = separator (byte 0), 1..k = bytes that label an edge, k + 1 = every other byte
+	bool is_label[256] = {};
+	for (const Edge &e : edges_) is_label[e.byte] = true;
+	is_label[0] = false; // edges labelled NUL are left out
+	uint32_t k = 0;
+	for (uint32_t b = 1; b < 256; b++)
+		if (is_label[b]) k++;
+	if (k + 2 > StreamImage::kCodes) return false;
+	const uint32_t other = k + 1;
+	{
+		uint32_t next = 1;
+		out->code[0] = 0;
+		for (uint32_t b = 1; b < 256; b++) out->code[b] = (uint8_t)(is_label[b] ? next++ : other);
+	}
+	// Rows widest first (packs tightest).  The image is used only when ALL of it fits in LDS, so
+	// unlike Pack there is nothing to gain from a hot-first order.  Nodes below an edge labelled
+	// NUL are unreachable and get no row (node numbers are breadth-first: parents come first).
+	std::vector<uint8_t> reach(N, 0);
+	reach[0] = 1;
+	for (uint32_t n = 0; n < N; n++) {
+		if (!reach[n]) continue;
+		const Edge *e = edges_.data() + first_child_[n];
+		for (uint32_t i = 0; i < n_children_[n]; i++)
+			if (e[i].byte != 0) reach[e[i].child] = 1;
+	}
+	std::vector<uint32_t> parents;
+	for (uint32_t n = 1; n < N; n++)
+		if (n_children_[n] && reach[n]) parents.push_back(n);
+	std::stable_sort(parents.begin(), parents.end(), [&](uint32_t a, uint32_t b) { return n_children_[a] > n_children_[b]; });
+	// first-fit placement over a free-slot chain (slots only ever go from free to used)
+	std::vector<uint8_t> used(4096, 0), base_used(4096, 0);
+	std::vector<uint32_t> next_free(4096);
+	for (uint32_t i = 0; i < 4096; i++) next_free[i] = i;
+	auto ensure = [&](uint64_t n) {
+		if (used.size() < n) {
+			const uint64_t old = used.size(), m = std::max<uint64_t>(n, old * 2);
+			used.resize(m, 0);
+			base_used.resize(m, 0);
+			next_free.resize(m);
+			for (uint64_t i = old; i < m; i++) next_free[i] = (uint32_t)i;
+		}
+	};
+	auto find_free = [&](uint64_t s) -> uint64_t {
+		ensure(s + 1);
+		uint64_t r = s;
+		while (next_free[r] != r) {
+			r = next_free[r];
+			ensure(r + 1);
+		}
+		while (next_free[s] != r) {
+			const uint64_t t = next_free[s];
+			next_free[s] = (uint32_t)r;
+			s = t;
+		}
+		return r;
+	};
+	uint64_t max_used = 0, max_base = 0;
+	auto place = [&](const uint32_t *codes, uint32_t nc) -> uint64_t {
+		const uint32_t c0 = codes[0];
+		uint64_t s = find_free(std::max<uint64_t>(1, (uint64_t)c0 + 1));
+		uint64_t b = 0;
+		for (uint32_t tries = 0;; tries++) {
+			b = s - c0;
+			ensure(b + StreamImage::kCodes + 1);
+			bool ok = !base_used[b];
+			for (uint32_t i = 0; ok && i < nc; i++) ok = !used[b + codes[i]];
+			if (ok) break;
+			if (tries >= 4096) { // (deep vocabularies: see Pack)
+				for (b = max_base + 1;; b++) {
+					ensure(b + StreamImage::kCodes + 1);
+					bool fits = true;
+					for (uint32_t i = 0; fits && i < nc; i++) fits = !used[b + codes[i]];
+					if (fits) break;
+				}
+				break;
+			}
+			s = find_free(s + 1);
+		}
+		base_used[b] = 1;
+		max_base = std::max(max_base, b);
+		for (uint32_t i = 0; i < nc; i++) {
+			const uint64_t slot = b + codes[i];
+			used[slot] = 1;
+			ensure(slot + 2);
+			next_free[slot] = (uint32_t)(slot + 1);
+			max_used = std::max(max_used, slot);
+		}
+		return b;
+	};
+	used[0] = 1; // slot 0 stays empty: node_sslot_ == 0 means "not in the image"
+	next_free[0] = 1;
+	std::vector<uint32_t> node_base(N, 0);
+	node_sslot_.assign(N, 0);
+	{
+		uint32_t all[StreamImage::kCodes];
+		for (uint32_t c = 0; c <= other; c++) all[c] = c;
+		node_base[0] = (uint32_t)place(all, other + 1); // the root row is dense
+		for (uint32_t i = 0; i < n_children_[0]; i++) {
+			const Edge &e = edges_[first_child_[0] + i];
+			if (e.byte != 0) node_sslot_[e.child] = node_base[0] + out->code[e.byte];
+		}
+	}
+	std::vector<uint32_t> codes;
+	for (uint32_t node : parents) {
+		const Edge *e = edges_.data() + first_child_[node];
+		codes.clear();
+		for (uint32_t i = 0; i < n_children_[node]; i++)
+			if (e[i].byte != 0) codes.push_back(out->code[e[i].byte]); // bytes ascending = codes ascending
+		if (codes.empty()) continue;
+		const uint32_t b = (uint32_t)place(codes.data(), (uint32_t)codes.size());
+		node_base[node] = b;
+		for (uint32_t i = 0; i < n_children_[node]; i++)
+			if (e[i].byte != 0) node_sslot_[e[i].child] = b + out->code[e[i].byte];
+		if (max_used + StreamImage::kCodes > StreamImage::kMaxSlots) return false;
+	}
+	const uint64_t nslots = std::max(max_used + 1, max_base + StreamImage::kCodes); // base + any code is a readable slot
+	if (nslots > StreamImage::kMaxSlots) return false;
+	out->lt.assign(nslots, 0);
+	out->base.assign(nslots, 0);
+	out->slot_id.assign(nslots, StreamImage::kSkipSlot);
+	out->root_base = node_base[0];
+	for (uint32_t c = 0; c <= other; c++) { // root slots without a child of their own
+		const uint32_t t = node_base[0] + c;
+		out->lt[t] = (uint8_t)(c | 0x80u);
+		out->slot_id[t] = c == 0 ? StreamImage::kSkipSlot : (uint32_t)(V_ + 2);
+	}
+	for (uint32_t node = 1; node < N; node++) {
+		const uint32_t t = node_sslot_[node];
+		if (!t) continue;
+		StreamSlotValues(node, out->lt[t] & 0x7Fu, &out->lt[t], &out->slot_id[t]); // (the code is filled in below)
+		out->base[t] = (uint16_t)node_base[node];
+	}
+	// codes of the real nodes: walk the edges
+	for (uint32_t node = 0; node < N; node++) {
+		if (node != 0 && node_sslot_[node] == 0) continue;
+		const Edge *e = edges_.data() + first_child_[node];
+		for (uint32_t i = 0; i < n_children_[node]; i++) {
+			if (e[i].byte == 0) continue;
+			const uint32_t t = node_sslot_[e[i].child];
+			out->lt[t] = (uint8_t)((out->lt[t] & 0x80u) | out->code[e[i].byte]);
+		}
+	}
+	out->valid = true;
+	return true;
+}
+
+int64_t VocabTrie::PatchStream(uint64_t token, StreamImage *img) const {
+	if (token >= V_ || !img->valid || node_sslot_.empty()) return -1;
+	const uint32_t node = tok_node_[token];
+	if (node == 0) return -1;
+	const uint32_t t = node_sslot_[node];
+	if (!t) return -1;
+	uint8_t lt;
+	uint32_t id;
+	StreamSlotValues(node, img->lt[t] & 0x7Fu, &lt, &id);
+	if (lt == img->lt[t] && id == img->slot_id[t]) return -1;
+	img->lt[t] = lt;
+	img->slot_id[t] = id;
+	return t;
+}
+
 uint32_t VocabTrie::StringRows(uint64_t nslots, std::vector<int32_t> *slot_row, std::vector<int32_t> *tok_row) const {
 	slot_row->assign(nslots, -1);
 	tok_row->assign(V_, -1);

@@ -40,6 +40,33 @@ struct PackedTrie {
 	static bool matches(uint64_t e, uint32_t c) { return ((uint32_t)e & kKeyMask) == (c | kValid); }
 };
 
+// The stream scan's image of the vocabulary (kernels_stream.hip; VocabTrie::PackStream): a second
+// double array, 3 bytes per slot instead of 8, small enough for a 32k-token vocabulary to sit in the
+// 160 KB of LDS whole.  It lives in CODE space: the bytes that label some trie edge get the codes
+// 1 .. k (k <= 125), byte 0 -- the separator the prepared corpus stores after every document -- is
+// code 0, every other byte shares the code k + 1 ("no edge has this label"); the prepared corpus
+// is stored as codes, so a lookup is slot t = base + code:
+//   lt[t]      label code (7 bits) | 0x80 when a token ends on the slot
+//   base[t]    base of the node's own children, 0 = none (full 16 bits: bases are unique per node,
+//              and with most nodes having children every value is needed)
+//   slot_id[t] the id a token end on the slot counts for (only the histogram's reduction reads it)
+// The root row is dense and every slot of it a token end: a byte that is no token of its own counts
+// as UNKNOWN (SolutionFile.cpp:92-94), code 0 as nothing (kSkipSlot).  Edges labelled with byte 0 are
+// left out: documents hold no NUL (DataFile.cpp:27-29), so they can never be followed, and no walk
+// may continue over a separator (the window clip of SolutionFile.cpp:90).  Empty slots are all
+// zero: only code 0 "hits" them, finds base 0 and no token end, which is what a miss does.
+struct StreamImage {
+	static constexpr uint64_t kMaxSlots = 65534;        // slot indices travel as u16 stream entries (0xFFFF = null)
+	static constexpr uint32_t kSkipSlot = 0xFFFFFFFFu;
+	static constexpr uint32_t kCodes = 128;
+	std::vector<uint8_t> lt;
+	std::vector<uint16_t> base;
+	std::vector<uint32_t> slot_id;
+	uint8_t code[256] = {};
+	uint32_t root_base = 0;
+	bool valid = false;
+};
+
 class VocabTrie {
 public:
 	// Token i = bytes[off[i]..off[i+1]).  Returns false (with *err set) when no token
@@ -57,6 +84,13 @@ public:
 	// Enable/disable token i; returns the slot whose id field changed (or -1) and the
 	// new packed value for it so the caller can patch the device copy.
 	int64_t Toggle(uint64_t token, bool enable, PackedTrie *packed, uint64_t *new_entry);
+
+	// The stream image (hot-first like Pack).  False when it cannot be built: more than 125
+	// distinct edge labels, or more than StreamImage::kMaxSlots slots.
+	bool PackStream(StreamImage *out);
+	// After Toggle(token): bring the image's slot of that token's node up to date; returns the
+	// slot (or -1 when the node is not in the image / nothing changed).
+	int64_t PatchStream(uint64_t token, StreamImage *img) const;
 
 	// Rows of a per-string table (one row per distinct non-empty token string): slot_row[t] = row
 	// of the node at slot t or -1, tok_row[i] = row of token i's string or -1.  After Pack.
@@ -92,6 +126,8 @@ private:
 	std::vector<uint32_t> tok_node_;  // node of token i (0 for empty strings)
 	std::vector<uint8_t> enabled_;
 	std::vector<uint32_t> node_slot_; // filled by Pack
+	std::vector<uint32_t> node_sslot_; // filled by PackStream: slot in the stream image, 0 = not in it
+	void StreamSlotValues(uint32_t node, uint32_t code, uint8_t *lt, uint32_t *slot_id) const;
 	bool sampled_ = false;
 };
 
