@@ -94,13 +94,18 @@ struct StreamWork {
 	uint32_t nranges;
 	uint32_t *entry;           // ... [nranges] entry overshoot the range's counted chain starts with
 	uint32_t *exit_a;          // ... [nranges] exit overshoot, written by the scan
+	const uint8_t *tprep;      // ... the ranges transposed in 8-byte pieces, 64 to a block of (range_bytes + halo) * 64 bytes
+	uint32_t halo;             //     bytes of the next range stored after each (multiple of 8)
+	uint32_t round;            //     lookups between two ring refills
 	const uint32_t *sel_list;  // incremental re-score: selected chunks (or nullptr) ...
 	const uint32_t *sel_count; // ... and their number
 	const uint32_t *chunk_first; // [nchunks + 1] first stream of every chunk
 	uint32_t streams_per_chunk;  // upper bound of the streams in one chunk
 };
 struct StreamScanPlan {
-	uint32_t ring;            // bytes of a lane's LDS ring (64 or 128)
+	uint32_t ring;            // bytes of a lane's LDS ring
+	uint32_t round = 16;      // lookups between two refills
+	uint32_t halo = 0;        // scan_ranges_kernel: bytes of the next range a block stores after each range
 	uint32_t waves_per_block;
 	uint32_t blocks;
 	uint32_t lds_bytes;
@@ -109,6 +114,12 @@ void launch_prep_corpus(const CorpusDev &C, const ByteCodes &M, uint8_t *prep, u
                         hipStream_t stream);
 bool plan_stream_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan);
 void launch_scan_stream(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
+                        hipStream_t stream);
+// full evaluation over the transposed ranges (W.tprep)
+bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan);
+void launch_transpose_ranges(const uint8_t *prep, uint64_t prep_readable, uint32_t range_bytes, uint32_t halo, uint32_t nblocks,
+                             uint8_t *tprep, hipStream_t stream);
+void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
                         hipStream_t stream);
 // out[slot_id[s]] += occurrences of slot s in the stream, out[total_index] += entries on counted slots
 void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,

@@ -41,6 +41,7 @@ namespace {
 
 #define LDS_AS __attribute__((address_space(3)))
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void wave_fence() {
 	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -282,6 +283,133 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	log.finish(Qd, lane);
 }
 
+// ---- full evaluation: equal ranges, refilled from the transposed corpus -------------------------
+// The ranges of one wave (64 consecutive ones) are stored interleaved in 8-byte pieces, piece k of
+// lane l's range at block + (k * 64 + l) * 8 (transpose_ranges_kernel), each range followed by
+// `halo` bytes of the next.  The 64 lanes of a wave advance at nearly the same pace, so a refill --
+// every lane that has room loads its next piece -- reads a few whole cache lines instead of 64
+// different ones, and 8-byte pieces let a lane's LDS ring be 32 bytes (plan_ranges_scan): with the
+// 1 KiB log block a wave needs 3 KiB of LDS, and sixteen waves fit beside the trie image.
+// Ring invariant, pieces of u = 8 bytes and rounds of K lookups (K <= u): RING >= 2 K + u + max_len - 2.
+// At the start of a round, after the piece asked for a round ago has landed, the ring holds
+// [fill - RING, fill) with lend >= fill - RING (nothing a walk can come back to is overwritten:
+// a piece is only asked for while fill - lend <= RING - u) and fill - cp > K (a round reads bytes
+// below cp + K + 1): a lane without a request has fill - cp >= RING - u - max_len + 3, loses at
+// most K per round until its next piece lands, and gains u - K >= 0 per round after that.
+template <uint32_t RING>
+__global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, StreamWork W, StreamDev Qd) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char ranges_smem[];
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)ranges_smem;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = uni32(threadIdx.x >> 6);
+	const uint32_t waves = blockDim.x >> 6;
+	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
+	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
+	{
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
+		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		dst = (LDS_AS u32x4 *)(lds + label_bytes);
+		src = reinterpret_cast<const u32x4 *>(T.base);
+		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+	}
+	__syncthreads();
+	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
+	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
+	LDS_AS unsigned char *wbase = lds + label_bytes + info_bytes + wave * (64 * RING + kLogEntries * 2);
+	LDS_AS unsigned char *ring = wbase + lane * RING;
+	WaveLog log;
+	log.init((LDS_AS uint16_t *)(wbase + 64 * RING), lane);
+
+	const uint32_t total_waves = gridDim.x * waves;
+	const uint32_t rows = W.range_bytes + W.halo; // bytes a lane's range has in its block (multiple of 8)
+	const uint32_t round = W.round;
+	for (uint32_t wb = blockIdx.x * waves + wave; wb * 64 < W.nranges; wb += total_waves) {
+		const uint32_t g = wb * 64 + lane;
+		// byte x (a multiple of 8) of this lane's range starts the piece at blk + x * 64
+		const uint8_t *blk = W.tprep + (size_t)wb * rows * 64 + lane * 8;
+		uint32_t end = 0, cp = 0;
+		if (g < W.nranges) {
+			const uint32_t b = g * W.range_bytes;
+			end = b + W.range_bytes < W.prep_total ? W.range_bytes : W.prep_total - b;
+			cp = W.entry[g]; // (may lie at or past `end`: the chain jumps the whole range)
+		}
+		bool active = cp < end;
+		uint32_t lend = cp, lslot = 0, nb = T.root_base;
+		uint32_t fill = cp & ~7u;
+		wave_fence();
+		if (active) {
+#pragma unroll
+			for (uint32_t k = 0; k < RING / 8; k++) {
+				const u32x2 x = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
+				*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = x;
+				fill += 8;
+			}
+		}
+		wave_fence();
+		bool req = false;
+		u32x2 data = {0, 0};
+		unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+		while (act != 0) {
+			if (req) {
+				*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = data;
+				fill += 8;
+			}
+			req = active && (fill - lend) <= RING - 8;
+			if (req) data = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
+			wave_fence();
+			for (uint32_t it = 0; it < round; it++) {
+				bool done = false;
+				if (active) {
+					const uint32_t c = ring[cp & (RING - 1)];
+					const uint32_t t = nb + c;
+					const uint32_t x = l_lt[t] ^ c;
+					const uint32_t b = l_base[t];
+					const uint32_t cp1 = cp + 1;
+					const bool term = x == 0x80u;
+					lend = term ? cp1 : lend;
+					lslot = term ? t : lslot;
+					nb = (x & 0x7Fu) == 0 ? b : 0u;
+					const bool cont = nb != 0;
+					cp = cont ? cp1 : lend;
+					done = !cont;
+				}
+				log.put(done, lslot);
+				if (done) {
+					nb = T.root_base;
+					active = cp < end;
+				}
+				if (log.cur > kLogHigh) log.flush(Qd, lane);
+				act = __builtin_amdgcn_ballot_w64(active);
+				if (act == 0) break;
+			}
+		}
+		if (g < W.nranges) W.exit_a[g] = cp - end;
+	}
+	log.finish(Qd, lane);
+}
+
+// tprep block wb, piece k, lane l = the 8 bytes prep[(wb * 64 + l) * range_bytes + 8 k ...] (zero past
+// what is readable of the linear copy).  One thread per piece.
+__global__ void __launch_bounds__(256) transpose_ranges_kernel(const uint8_t *prep, uint64_t prep_readable, uint32_t range_bytes,
+                                                               uint32_t halo, uint32_t nblocks, uint8_t *tprep) {
+	const uint64_t pieces = ((uint64_t)range_bytes + halo) / 8; // per range
+	const uint64_t n = (uint64_t)nblocks * pieces * 64;
+	for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+		const uint64_t wb = i / (pieces * 64);
+		const uint64_t rem = i - wb * pieces * 64;
+		const uint64_t k = rem / 64;
+		const uint64_t l = rem % 64;
+		const uint64_t src = (wb * 64 + l) * range_bytes + 8 * k;
+		uint32_t w[2] = {0, 0};
+		for (uint32_t j = 0; j < 8; j++) {
+			const uint32_t c = src + j < prep_readable ? prep[src + j] : 0u;
+			w[j >> 2] |= c << (8 * (j & 3));
+		}
+		reinterpret_cast<uint2 *>(tprep)[i] = uint2{w[0], w[1]};
+	}
+}
+
 // ---- range entries: fix-up ------------------------------------------------------------------
 // The protocol of kernels_generic.hip's fix-up (fixup_parallel_kernel / fixup_ordered_kernel), on
 // the prepared corpus and the stream image read from global memory.  Range g counted the chain
@@ -511,6 +639,61 @@ bool plan_stream_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, Strea
 	plan->blocks = num_cus;
 	plan->lds_bytes = label_bytes + info_bytes + waves * wave_bytes;
 	return true;
+}
+
+void launch_transpose_ranges(const uint8_t *prep, uint64_t prep_readable, uint32_t range_bytes, uint32_t halo, uint32_t nblocks,
+                             uint8_t *tprep, hipStream_t stream) {
+	const uint64_t n = (uint64_t)nblocks * ((range_bytes + halo) / 8) * 64;
+	if (n == 0) return;
+	const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 1u << 16);
+	hipLaunchKernelGGL(transpose_ranges_kernel, dim3(blocks), dim3(256), 0, stream, prep, prep_readable, range_bytes, halo, nblocks,
+	                   tprep);
+}
+
+bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan) {
+	// RING >= 2 K + 8 + max_len - 2 with rounds of K <= 8 lookups (scan_ranges_kernel); a round
+	// shorter than 4 spends too much on refills: the next ring size then
+	uint32_t ring = 0, round = 0;
+	for (uint32_t r : {32u, 64u, 128u}) {
+		if (r < 6 + max_len + 2) continue;
+		const uint32_t k = std::min<uint32_t>(8, (uint32_t)((r - 6 - max_len) / 2));
+		if (k >= 4) {
+			ring = r, round = k;
+			break;
+		}
+	}
+	if (!ring) return false;
+	if (const char *s = getenv("TOKSCORE_RING")) {
+		const uint32_t r = (uint32_t)atoi(s);
+		if ((r == 64 || r == 128) && r > ring) ring = r, round = std::min<uint32_t>(8, (uint32_t)((r - 6 - max_len) / 2));
+	}
+	const uint32_t label_bytes = (nslots + 15) & ~15u;
+	const uint32_t info_bytes = (nslots * 2 + 15) & ~15u;
+	const uint32_t wave_bytes = 64 * ring + kLogEntries * 2;
+	const uint32_t lds_total = 160 * 1024 - 64;
+	if (label_bytes + info_bytes + 4 * wave_bytes > lds_total) return false;
+	uint32_t waves = (lds_total - label_bytes - info_bytes) / wave_bytes;
+	if (waves > 16) waves = 16;
+	if (const char *s = getenv("TOKSCORE_WAVES")) waves = std::min<uint32_t>(waves, (uint32_t)std::max(1, atoi(s)));
+	plan->ring = ring;
+	plan->round = round;
+	plan->halo = (ring + 2 * (uint32_t)max_len + 2 + 7) & ~7u;
+	plan->waves_per_block = waves;
+	plan->blocks = num_cus;
+	plan->lds_bytes = label_bytes + info_bytes + waves * wave_bytes;
+	return true;
+}
+
+void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
+                        hipStream_t stream) {
+	auto go = [&](auto kernel) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                          (int)plan.lds_bytes);
+		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, T, W, Q);
+	};
+	if (plan.ring == 32) go(&scan_ranges_kernel<32>);
+	else if (plan.ring == 64) go(&scan_ranges_kernel<64>);
+	else go(&scan_ranges_kernel<128>);
 }
 
 void launch_scan_stream(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,

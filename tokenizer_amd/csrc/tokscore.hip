@@ -141,6 +141,9 @@ struct tokscore_ctx {
 	uint32_t range_bytes = 0;        // full evaluation: equal ranges of the prepared corpus, one per lane
 	uint32_t nranges = 0;
 	uint32_t *d_range_state = nullptr; // entry | exit_a | exit_b, nranges words each
+	uint8_t *d_tprep = nullptr;      // the ranges transposed, 64 to a block (kernels_stream.hip: scan_ranges_kernel)
+	uint32_t halo = 0;
+	StreamScanPlan rplan = {};       // launch of scan_ranges_kernel
 	uint8_t *h_patch_lt = nullptr;    // pinned, beside h_patch
 	uint32_t *h_patch_id = nullptr;
 
@@ -253,6 +256,8 @@ void free_plan(tokscore_ctx *c) {
 	c->d_chunk_first = nullptr;
 	if (c->d_range_state) (void)hipFree(c->d_range_state);
 	c->d_range_state = nullptr;
+	if (c->d_tprep) (void)hipFree(c->d_tprep);
+	c->d_tprep = nullptr;
 	c->d_chunk_begin = nullptr;
 	c->d_chunk_state = nullptr;
 	c->d_stream = nullptr;
@@ -315,6 +320,9 @@ StreamWork stream_work(const tokscore_ctx *c, bool selected) {
 	W.nranges = c->nranges;
 	W.entry = c->d_range_state;
 	W.exit_a = c->d_range_state + c->nranges;
+	W.tprep = c->d_tprep;
+	W.halo = c->halo;
+	W.round = c->rplan.round;
 	W.sel_list = selected ? c->d_sel_list : nullptr;
 	W.sel_count = selected ? c->d_sel_list + c->nchunks : nullptr;
 	W.chunk_first = c->d_chunk_first;
@@ -521,14 +529,35 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 	c->streams_per_chunk = (uint32_t)spc;
 	c->splan = sp;
 	// full evaluation: as many equal ranges as the grid has lanes (none shorter than four tokens)
-	const uint64_t lanes = (uint64_t)sp.blocks * sp.waves_per_block * 64;
+	StreamScanPlan rp = sp;
+	const bool transposed = !env_u64("TOKSCORE_NOTRANSPOSE", 0) &&
+	                        plan_ranges_scan((uint32_t)c->simg.lt.size(), c->packed.max_len, (uint32_t)c->num_cus, &rp);
+	if (!transposed) rp = sp;
+	c->rplan = rp;
+	const uint64_t lanes = (uint64_t)rp.blocks * rp.waves_per_block * 64;
 	uint64_t rb = (c->prep_total + lanes - 1) / lanes;
 	rb = std::max<uint64_t>(rb, std::max<uint64_t>(64, 4 * c->packed.max_len));
 	rb = std::max<uint64_t>(rb, env_u64("TOKSCORE_RANGE", 0));
+	rb = (rb + 7) & ~7ull;
 	c->range_bytes = (uint32_t)rb;
 	c->nranges = (uint32_t)((c->prep_total + rb - 1) / rb);
 	HIP_TRY(c, hipMalloc((void **)&c->d_range_state, (size_t)3 * c->nranges * sizeof(uint32_t)));
 	HIP_TRY(c, hipMemset(c->d_range_state, 0, (size_t)3 * c->nranges * sizeof(uint32_t)));
+	if (transposed) {
+		// each range is followed by the first bytes of the next: a walk may look max_len bytes past a
+		// token that itself ends max_len - 1 bytes past the range
+		c->halo = rp.halo;
+		const uint64_t nblocks = ((uint64_t)c->nranges + 63) / 64;
+		const uint64_t tbytes = nblocks * (rb + c->halo) * 64;
+		if (hipMalloc((void **)&c->d_tprep, tbytes) == hipSuccess) {
+			launch_transpose_ranges(c->d_prep, c->prep_total + kCorpusPad, (uint32_t)rb, c->halo, (uint32_t)nblocks, c->d_tprep, c->stream);
+			HIP_TRY(c, hipStreamSynchronize(c->stream));
+		} else {
+			(void)hipGetLastError();
+			c->d_tprep = nullptr; // no room: the ring scan over the linear copy does the full evaluations too
+			c->rplan = sp;
+		}
+	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_pbeg, (ns + 1) * sizeof(uint32_t)));
 	HIP_TRY(c, hipMemcpy(c->d_pbeg, pb.data(), (ns + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
 	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_begin, c->h_chunk_begin.size() * sizeof(uint64_t)));
@@ -539,7 +568,7 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 	HIP_TRY(c, hipMalloc((void **)&c->d_sel_list, ((size_t)c->nchunks + 1) * sizeof(uint32_t)));
 	// token stream: at most one entry per prepared byte (every token and every separator is at
 	// least one byte), so this capacity cannot be exceeded whatever the input
-	const uint64_t batches = stream_scan_capacity_batches(c->prep_total, sp.blocks * sp.waves_per_block);
+	const uint64_t batches = stream_scan_capacity_batches(c->prep_total, sp.blocks * 16);
 	if (batches > 0x7FFFFFF0ull) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one token stream");
 	c->stream_cap_batches = (uint32_t)batches;
 	HIP_TRY(c, hipMalloc(&c->d_stream, batches * kStreamBatch * 1024));
@@ -722,7 +751,8 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s);
 		HIP_TRY(c, mark(1));
 		const StreamWork W = stream_work(c, false);
-		launch_scan_stream(stream_trie_dev(c), W, Q, c->splan, s);
+		if (c->d_tprep) launch_scan_ranges(stream_trie_dev(c), W, Q, c->rplan, s);
+		else launch_scan_stream(stream_trie_dev(c), W, Q, c->splan, s);
 		HIP_TRY(c, mark(2));
 		// ranges whose entry was not the previous range's exit (none while the vocabulary stays as it is)
 		launch_fixup_stream(stream_trie_dev(c), c->d_slot_id, W, c->d_range_state + 2 * (size_t)c->nranges, c->d_cursor + 2, d_out,
