@@ -227,7 +227,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 		}
 		const bool has_range = !W.sel_list && item < n_items;
 		bool active = beg < end;
-		uint32_t cp = beg, lend = beg, lslot = 0, nb = T.root_base;
+		uint32_t cp = beg, lend = beg, lslot = 0, nb = 0; // (the root's base is 0)
 		uint32_t fill = beg & ~15u;
 		wave_fence();
 		if (active) {
@@ -269,10 +269,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 					done = !cont;
 				}
 				log.put(done, lslot);
-				if (done) {
-					nb = T.root_base;
-					active = cp < end;
-				}
+				if (done) active = cp < end; // (nb is 0 = the root again)
 				if (log.cur > kLogHigh) log.flush(Qd, lane);
 				act = __builtin_amdgcn_ballot_w64(active);
 				if (act == 0) break;
@@ -296,7 +293,99 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 // a piece is only asked for while fill - lend <= RING - u) and fill - cp > K (a round reads bytes
 // below cp + K + 1): a lane without a request has fill - cp >= RING - u - max_len + 3, loses at
 // most K per round until its next piece lands, and gains u - K >= 0 per round after that.
-template <uint32_t RING>
+//
+// The loop over rounds is hand-written gfx950 assembly (TOK_RANGES_ASM): the scan is bound by the
+// number of instructions a SIMD has to issue per lookup and by the two dependent LDS round trips
+// of a lookup (byte, then slot), so what counts is the instruction count, scalar ones included,
+// and that the next byte's read is under way while the finished tokens are logged.  Per lookup:
+// 17 vector, 4 LDS and 12 scalar instructions, plus 15 per round for the refill (the compiler's
+// code for the same loop, kept below for TOKSCORE_ASM=0, needs about 50 per lookup).
+// Conventions: exec = lanes still inside their range (ACT); v24 = the byte at cp, read at the end of
+// the previous lookup; v25-v29, s[38:43] scratch; IT = lookups left in the round - 1, all ones = a
+// round starts (refill first).  The block is left when no lane is active any more or when the log
+// block may not take another lookup (the C++ around it flushes and comes back), with nothing in
+// flight.
+#define TOK_RANGES_ASM(HIGH)                                                                 \
+	asm volatile(                                                                             \
+	    "s_mov_b64 s[38:39], exec\n"                                                          \
+	    "s_mov_b64 %[act], %[actin]\n"                                                        \
+	    "s_mov_b64 %[req], %[reqin]\n"                                                        \
+	    "s_mov_b32 %[cur], %[curin]\n"                                                        \
+	    "s_mov_b32 %[it], %[itin]\n"                                                          \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
+	    "ds_read_u8 v24, v25\n"                                                               \
+	    "s_cmp_eq_u32 %[it], -1\n"                                                            \
+	    "s_cbranch_scc1 .Lround%=\n"                                                          \
+	    ".Ltop%=:\n"                                                                          \
+	    "s_waitcnt lgkmcnt(0)\n"                                                              \
+	    "v_add_u32 v25, %[nb], v24\n"                 /* slot t = LDS address of lt[t]     */ \
+	    "v_lshl_add_u32 v26, v25, 1, %[basea]\n"      /* address of base[t]                */ \
+	    "ds_read_u8 v27, v25\n"                                                               \
+	    "ds_read_u16 v28, v26\n"                                                              \
+	    "v_add_u32 v29, 1, %[cp]\n"                                                           \
+	    "s_waitcnt lgkmcnt(0)\n"                                                              \
+	    "v_xor_b32 v27, v27, v24\n"                   /* 0x80 hit on a token end, 0 hit    */ \
+	    "v_cmp_eq_u32 vcc, 0x80, v27\n"                                                       \
+	    "v_cndmask_b32 %[lend], %[lend], v29, vcc\n"                                          \
+	    "v_cndmask_b32 %[lslot], %[lslot], v25, vcc\n"                                        \
+	    "v_and_b32 v27, 0x7f, v27\n"                                                          \
+	    "v_cmp_eq_u32 vcc, 0, v27\n"                                                          \
+	    "v_cndmask_b32 %[nb], 0, v28, vcc\n"          /* miss or leaf: 0 = the root again  */ \
+	    "v_cmp_ne_u32 vcc, 0, %[nb]\n"                                                        \
+	    "v_cndmask_b32 %[cp], %[lend], v29, vcc\n"    /* goes on, or next token's start    */ \
+	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
+	    "ds_read_u8 v24, v25\n"                                                               \
+	    "s_andn2_b64 s[42:43], exec, vcc\n"           /* lanes whose token is complete     */ \
+	    "s_mov_b64 exec, s[42:43]\n"                                                          \
+	    "v_mbcnt_lo_u32_b32 v26, s42, 0\n"                                                    \
+	    "v_mbcnt_hi_u32_b32 v26, s43, v26\n"          /* rank among them                   */ \
+	    "v_lshl_add_u32 v26, v26, 1, %[cur]\n"        /* log cell (cur = address of the next free one) */ \
+	    "ds_write_b16 v26, %[lslot]\n"                                                        \
+	    "s_bcnt1_i32_b64 s40, s[42:43]\n"                                                     \
+	    "s_lshl1_add_u32 %[cur], s40, %[cur]\n"                                               \
+	    "v_cmp_ge_u32 vcc, %[cp], %[hi]\n"            /* range done                        */ \
+	    "s_andn2_b64 %[act], %[act], vcc\n"                                                   \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    "s_add_u32 %[it], %[it], -1\n"                /* carry = lookups left in the round */ \
+	    "s_cbranch_scc0 .Lround%=\n"                                                          \
+	    ".Lcheck%=:\n"                                                                        \
+	    "s_cmp_gt_u32 %[cur], %[high]\n"                                                      \
+	    "s_cbranch_scc0 .Ltop%=\n"                                                            \
+	    "s_branch .Lout%=\n"                                                                  \
+	    ".Lround%=:\n"                                /* refill, then the next round       */ \
+	    "s_cmp_eq_u64 %[act], 0\n"                                                            \
+	    "s_cbranch_scc1 .Lout%=\n"                                                            \
+	    "s_waitcnt vmcnt(0)\n"                                                                \
+	    "s_mov_b64 exec, %[req]\n"                    /* the piece asked for a round ago   */ \
+	    "v_and_or_b32 v25, %[fill], %[rmask], %[rbase]\n"                                     \
+	    "ds_write_b64 v25, %[data]\n"                                                         \
+	    "v_add_u32 %[fill], 8, %[fill]\n"                                                     \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    "v_sub_u32 v25, %[fill], %[lend]\n"                                                   \
+	    "v_cmp_ge_u32 vcc, %[room], v25\n"            /* room for another piece            */ \
+	    "s_mov_b64 %[req], vcc\n"                                                             \
+	    "s_mov_b64 exec, vcc\n"                                                               \
+	    "v_lshl_add_u32 v25, %[fill], 6, %[tb]\n"                                             \
+	    "s_waitcnt lgkmcnt(0)\n"                      /* (data is free again)              */ \
+	    "global_load_dwordx2 %[data], v25, %[tprep]\n"                                        \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
+	    "ds_read_u8 v24, v25\n"                                                               \
+	    "s_mov_b32 %[it], %[km1]\n"                                                           \
+	    "s_branch .Lcheck%=\n"                                                                \
+	    ".Lout%=:\n"                                                                          \
+	    "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                     \
+	    "s_mov_b64 exec, s[38:39]\n"                                                          \
+	    : [cp] "+v"(cp), [nb] "+v"(nb), [lend] "+v"(lend), [lslot] "+v"(lslot), [fill] "+v"(fill),      \
+	      [data] "+v"(data), [act] "=&s"(act_out), [req] "=&s"(req_out), [cur] "=&s"(cur_out),          \
+	      [it] "=&s"(it_out)                                                                            \
+	    : [actin] "s"(uni64(act)), [reqin] "s"(uni64(req)), [curin] "s"(uni32(log_a + 2 * log.cur)), [itin] "s"(uni32(it)), \
+	      [hi] "v"(end), [rbase] "v"(ring_a), [tb] "v"(tb), [rmask] "s"(RING - 1), [basea] "s"(label_bytes), \
+	      [high] "s"(log_a + 2 * HIGH), [room] "s"(RING - 8), [km1] "s"(round - 1), [tprep] "s"(W.tprep)           \
+	    : "v24", "v25", "v26", "v27", "v28", "v29", "s38", "s39", "s40", "s41", "s42", "s43", "vcc", "scc", "memory")
+
+template <uint32_t RING, bool ASM>
 __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, StreamWork W, StreamDev Qd) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ranges_smem[];
 	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)ranges_smem;
@@ -316,7 +405,14 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 	__syncthreads();
 	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
 	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
-	LDS_AS unsigned char *wbase = lds + label_bytes + info_bytes + wave * (64 * RING + kLogEntries * 2);
+	if (ASM && (uint32_t)(uintptr_t)lds != 0) {
+		// the assembly takes a slot index for the LDS address of its label (the image starts at LDS
+		// address 0: this kernel has no static LDS); reported like a stream overflow, never ignored
+		if (threadIdx.x == 0) Qd.cursor[1] = 1u;
+		return;
+	}
+	// (ring bases are multiples of the ring size: the assembly ORs a ring offset into them)
+	LDS_AS unsigned char *wbase = lds + ((label_bytes + info_bytes + 127) & ~127u) + wave * (64 * RING + kLogEntries * 2);
 	LDS_AS unsigned char *ring = wbase + lane * RING;
 	WaveLog log;
 	log.init((LDS_AS uint16_t *)(wbase + 64 * RING), lane);
@@ -335,7 +431,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 			cp = W.entry[g]; // (may lie at or past `end`: the chain jumps the whole range)
 		}
 		bool active = cp < end;
-		uint32_t lend = cp, lslot = 0, nb = T.root_base;
+		uint32_t lend = cp, lslot = 0, nb = 0; // (the root's base is 0)
 		uint32_t fill = cp & ~7u;
 		wave_fence();
 		if (active) {
@@ -347,41 +443,55 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 			}
 		}
 		wave_fence();
-		bool req = false;
-		u32x2 data = {0, 0};
-		unsigned long long act = __builtin_amdgcn_ballot_w64(active);
-		while (act != 0) {
-			if (req) {
-				*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = data;
-				fill += 8;
-			}
-			req = active && (fill - lend) <= RING - 8;
-			if (req) data = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
-			wave_fence();
-			for (uint32_t it = 0; it < round; it++) {
-				bool done = false;
-				if (active) {
-					const uint32_t c = ring[cp & (RING - 1)];
-					const uint32_t t = nb + c;
-					const uint32_t x = l_lt[t] ^ c;
-					const uint32_t b = l_base[t];
-					const uint32_t cp1 = cp + 1;
-					const bool term = x == 0x80u;
-					lend = term ? cp1 : lend;
-					lslot = term ? t : lslot;
-					nb = (x & 0x7Fu) == 0 ? b : 0u;
-					const bool cont = nb != 0;
-					cp = cont ? cp1 : lend;
-					done = !cont;
-				}
-				log.put(done, lslot);
-				if (done) {
-					nb = T.root_base;
-					active = cp < end;
-				}
+		if constexpr (ASM) {
+			const uint32_t ring_a = (uint32_t)(uintptr_t)ring;
+			const uint32_t log_a = uni32((uint32_t)(uintptr_t)log.cells);
+			const uint32_t tb = (uint32_t)((size_t)wb * rows * 64 + lane * 8); // (the transposed copy is below 4 GiB)
+			unsigned long long act = __builtin_amdgcn_ballot_w64(active), req = 0;
+			u32x2 data = {0, 0};
+			uint32_t it = 0xFFFFFFFFu;
+			while (act != 0) {
+				unsigned long long act_out, req_out;
+				uint32_t cur_out, it_out;
+				TOK_RANGES_ASM(kLogHigh);
+				act = act_out, req = req_out, it = it_out;
+				log.cur = (cur_out - log_a) / 2;
 				if (log.cur > kLogHigh) log.flush(Qd, lane);
-				act = __builtin_amdgcn_ballot_w64(active);
-				if (act == 0) break;
+			}
+		} else {
+			bool req = false;
+			u32x2 data = {0, 0};
+			unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+			while (act != 0) {
+				if (req) {
+					*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = data;
+					fill += 8;
+				}
+				req = active && (fill - lend) <= RING - 8;
+				if (req) data = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
+				wave_fence();
+				for (uint32_t it = 0; it < round; it++) {
+					bool done = false;
+					if (active) {
+						const uint32_t c = ring[cp & (RING - 1)];
+						const uint32_t t = nb + c;
+						const uint32_t x = l_lt[t] ^ c;
+						const uint32_t b = l_base[t];
+						const uint32_t cp1 = cp + 1;
+						const bool term = x == 0x80u;
+						lend = term ? cp1 : lend;
+						lslot = term ? t : lslot;
+						nb = (x & 0x7Fu) == 0 ? b : 0u;
+						const bool cont = nb != 0;
+						cp = cont ? cp1 : lend;
+						done = !cont;
+					}
+					log.put(done, lslot);
+					if (done) active = cp < end; // (nb is 0 = the root again)
+					if (log.cur > kLogHigh) log.flush(Qd, lane);
+					act = __builtin_amdgcn_ballot_w64(active);
+					if (act == 0) break;
+				}
 			}
 		}
 		if (g < W.nranges) W.exit_a[g] = cp - end;
@@ -432,10 +542,10 @@ struct FixDev {
 // one token of the chain at pos: its length and the slot it ends on (the root row is dense and
 // all token ends, so len >= 1; separators stop every walk)
 __device__ __forceinline__ void walk_token_image(const FixDev &F, uint32_t pos, uint32_t &len, uint32_t &slot) {
-	uint32_t nb = F.T.root_base, d = 0;
+	uint32_t nb = 0, d = 0; // the root's base is 0
 	len = 1;
 	slot = 0;
-	while (nb != 0) {
+	do {
 		const uint32_t c = F.prep[pos + d];
 		const uint32_t t = nb + c;
 		const uint32_t x = F.T.lt[t] ^ c;
@@ -443,7 +553,7 @@ __device__ __forceinline__ void walk_token_image(const FixDev &F, uint32_t pos, 
 		d++;
 		if (x == 0x80u) len = d, slot = t;
 		nb = F.T.base[t];
-	}
+	} while (nb != 0);
 }
 
 __device__ __forceinline__ void count_slot(const FixDev &F, uint32_t slot, bool add) {
@@ -671,8 +781,9 @@ bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, Strea
 	const uint32_t info_bytes = (nslots * 2 + 15) & ~15u;
 	const uint32_t wave_bytes = 64 * ring + kLogEntries * 2;
 	const uint32_t lds_total = 160 * 1024 - 64;
-	if (label_bytes + info_bytes + 4 * wave_bytes > lds_total) return false;
-	uint32_t waves = (lds_total - label_bytes - info_bytes) / wave_bytes;
+	const uint32_t image_bytes = (label_bytes + info_bytes + 127) & ~127u;
+	if (image_bytes + 4 * wave_bytes > lds_total) return false;
+	uint32_t waves = (lds_total - image_bytes) / wave_bytes;
 	if (waves > 16) waves = 16;
 	if (const char *s = getenv("TOKSCORE_WAVES")) waves = std::min<uint32_t>(waves, (uint32_t)std::max(1, atoi(s)));
 	plan->ring = ring;
@@ -680,7 +791,7 @@ bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, Strea
 	plan->halo = (ring + 2 * (uint32_t)max_len + 2 + 7) & ~7u;
 	plan->waves_per_block = waves;
 	plan->blocks = num_cus;
-	plan->lds_bytes = label_bytes + info_bytes + waves * wave_bytes;
+	plan->lds_bytes = image_bytes + waves * wave_bytes;
 	return true;
 }
 
@@ -691,9 +802,19 @@ void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const Strea
 		                          (int)plan.lds_bytes);
 		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, T, W, Q);
 	};
-	if (plan.ring == 32) go(&scan_ranges_kernel<32>);
-	else if (plan.ring == 64) go(&scan_ranges_kernel<64>);
-	else go(&scan_ranges_kernel<128>);
+	static const bool use_asm = [] {
+		const char *e = getenv("TOKSCORE_ASM");
+		return !(e && atoi(e) == 0);
+	}();
+	if (use_asm) {
+		if (plan.ring == 32) go(&scan_ranges_kernel<32, true>);
+		else if (plan.ring == 64) go(&scan_ranges_kernel<64, true>);
+		else go(&scan_ranges_kernel<128, true>);
+	} else {
+		if (plan.ring == 32) go(&scan_ranges_kernel<32, false>);
+		else if (plan.ring == 64) go(&scan_ranges_kernel<64, false>);
+		else go(&scan_ranges_kernel<128, false>);
+	}
 }
 
 void launch_scan_stream(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,

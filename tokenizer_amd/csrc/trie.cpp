@@ -367,14 +367,20 @@ bool VocabTrie::PackStream(StreamImage *out) {
 		}
 		return b;
 	};
-	used[0] = 1; // slot 0 stays empty: node_sslot_ == 0 means "not in the image"
-	next_free[0] = 1;
 	std::vector<uint32_t> node_base(N, 0);
 	node_sslot_.assign(N, 0);
 	{
-		uint32_t all[StreamImage::kCodes];
-		for (uint32_t c = 0; c <= other; c++) all[c] = c;
-		node_base[0] = (uint32_t)place(all, other + 1); // the root row is dense
+		// The root row is dense and sits at base 0: "no children" and "back at the root" are then
+		// the same value, and a walker that has finished a token is at the root without being reset.
+		// Slot 0 is the separator's (no node of the trie has it: node_sslot_ == 0 means "not in the image").
+		ensure(other + 2);
+		for (uint32_t c = 0; c <= other; c++) {
+			used[c] = 1;
+			next_free[c] = c + 1;
+		}
+		base_used[0] = 1;
+		max_used = other;
+		node_base[0] = 0;
 		for (uint32_t i = 0; i < n_children_[0]; i++) {
 			const Edge &e = edges_[first_child_[0] + i];
 			if (e.byte != 0) node_sslot_[e.child] = node_base[0] + out->code[e.byte];

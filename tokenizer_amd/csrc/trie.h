@@ -48,7 +48,8 @@ struct PackedTrie {
 // is stored as codes, so a lookup is slot t = base + code:
 //   lt[t]      label code (7 bits) | 0x80 when a token ends on the slot
 //   base[t]    base of the node's own children, 0 = none (full 16 bits: bases are unique per node,
-//              and with most nodes having children every value is needed)
+//              and with most nodes having children every value is needed).  The root's base is 0
+//              too: after a token's last slot the next lookup is at the root again.
 //   slot_id[t] the id a token end on the slot counts for (only the histogram's reduction reads it)
 // The root row is dense and every slot of it a token end: a byte that is no token of its own counts
 // as UNKNOWN (SolutionFile.cpp:92-94), code 0 as nothing (kSkipSlot).  Edges labelled with byte 0 are
