@@ -272,7 +272,7 @@ def main():
                        "trie_lds_slots": int(info.trie_lds_slots), "chunks": int(info.chunks),
                        "scan_path": {1: "lds_tile", 2: "lds_stream"}.get(int(info.scan_path), "generic"),
                        "parallelism": "documents sharded over %d GPU(s), 1 count all-reduce" % world},
-            "roofline": {"bound": "hbm", "kernel": {1: "scan_tile_kernel", 2: "scan_stream_kernel"}.get(int(info.scan_path), "scan_generic_kernel"),
+            "roofline": {"bound": "hbm", "kernel": {1: "scan_tile_kernel", 2: "scan_ranges_kernel"}.get(int(info.scan_path), "scan_generic_kernel"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": scan_avg_ms,
                          "eval_kernels_ms": float(np.mean(eval_ms)),

@@ -106,6 +106,7 @@ __global__ void __launch_bounds__(256) prep_corpus_kernel(CorpusDev C, ByteCodes
 }
 
 // ---- the scan ------------------------------------------------------------------------------
+constexpr uint32_t kBatchEntries = kStreamBatch * 512; // u16 entries of one stream batch (32 KiB); fill[batch] = entries written
 constexpr uint32_t kLogEntries = 512;               // u16 entries per wave log block = one stream block (1 KiB)
 constexpr uint32_t kLogHigh = kLogEntries - 64;     // flush above this fill
 constexpr uint32_t kRound = 16;                     // lookups between two ring refills
@@ -138,7 +139,7 @@ struct WaveLog {
 	__device__ __forceinline__ void flush(const StreamDev &S, uint32_t lane) {
 		constexpr uint32_t vecs = kLogEntries * 2 / 16;
 		if (used == kStreamBatch) {
-			if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = kStreamBatch;
+			if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = kBatchEntries;
 			uint32_t b = 0;
 			if (lane == 0) b = atomicAdd(&S.cursor[0], 1u);
 			batch = __builtin_amdgcn_readfirstlane(b);
@@ -159,7 +160,47 @@ struct WaveLog {
 	}
 	__device__ __forceinline__ void finish(const StreamDev &S, uint32_t lane) {
 		if (cur != 0) flush(S, lane);
-		if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = used;
+		if (lane == 0 && batch < S.capacity_batches) S.fill[batch] = used * kLogEntries;
+	}
+};
+
+// scan_ranges_kernel's log: no LDS block at all.  A wave owns one stream batch at a time and the
+// lanes that complete a token in a step store their 16-bit slot indices straight to it, at
+// consecutive positions (rank among them by mbcnt): one partial-line store per step that the L2
+// merges, one LDS instruction per lookup fewer, and a dense stream (no null padding to read back).
+struct DirectLog {
+	uint16_t *base;  // wave uniform: the current batch
+	uint32_t cur;    // wave uniform: bytes written to it
+	uint32_t batch;  // wave uniform
+	static constexpr uint32_t kHighBytes = kBatchEntries * 2 - 128; // a step adds at most 64 entries
+	__device__ __forceinline__ void open(const StreamDev &S, uint32_t lane) {
+		uint32_t b = 0;
+		if (lane == 0) b = atomicAdd(&S.cursor[0], 1u);
+		batch = __builtin_amdgcn_readfirstlane(b);
+		if (batch >= S.capacity_batches) {
+			// cannot happen (the stream is sized for one entry per prepared byte); reported all the same
+			if (lane == 0) S.cursor[1] = 1u;
+			batch = 0;
+		}
+		base = reinterpret_cast<uint16_t *>(S.blocks) + (size_t)batch * kBatchEntries;
+		cur = 0;
+	}
+	__device__ __forceinline__ void close(const StreamDev &S, uint32_t lane) {
+		if (lane == 0) S.fill[batch] = cur / 2;
+	}
+	__device__ __forceinline__ void roll_if_full(const StreamDev &S, uint32_t lane) {
+		if (cur > kHighBytes) {
+			close(S, lane);
+			open(S, lane);
+		}
+	}
+	__device__ __forceinline__ void put(bool pred, uint32_t val) { // wave-uniform call
+		const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+		if (pred) {
+			const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+			base[cur / 2 + rank] = (uint16_t)val;
+		}
+		cur += 2 * (uint32_t)__builtin_popcountll(m);
 	}
 };
 
@@ -298,7 +339,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 // number of instructions a SIMD has to issue per lookup and by the two dependent LDS round trips
 // of a lookup (byte, then slot), so what counts is the instruction count, scalar ones included,
 // and that the next byte's read is under way while the finished tokens are logged.  Per lookup:
-// 17 vector, 4 LDS and 12 scalar instructions, plus 15 per round for the refill (the compiler's
+// 17 vector, 3 LDS, 1 store and 12 scalar instructions, plus 15 per round for the refill (the compiler's
 // code for the same loop, kept below for TOKSCORE_ASM=0, needs about 50 per lookup).
 // Conventions: exec = lanes still inside their range (ACT); v24 = the byte at cp, read at the end of
 // the previous lookup; v25-v29, s[38:43] scratch; IT = lookups left in the round - 1, all ones = a
@@ -340,8 +381,8 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	    "s_mov_b64 exec, s[42:43]\n"                                                          \
 	    "v_mbcnt_lo_u32_b32 v26, s42, 0\n"                                                    \
 	    "v_mbcnt_hi_u32_b32 v26, s43, v26\n"          /* rank among them                   */ \
-	    "v_lshl_add_u32 v26, v26, 1, %[cur]\n"        /* log cell (cur = address of the next free one) */ \
-	    "ds_write_b16 v26, %[lslot]\n"                                                        \
+	    "v_lshl_add_u32 v26, v26, 1, %[cur]\n"        /* byte offset in the wave's stream batch */ \
+	    "global_store_short v26, %[lslot], %[sbase]\n"                                        \
 	    "s_bcnt1_i32_b64 s40, s[42:43]\n"                                                     \
 	    "s_lshl1_add_u32 %[cur], s40, %[cur]\n"                                               \
 	    "v_cmp_ge_u32 vcc, %[cp], %[hi]\n"            /* range done                        */ \
@@ -356,7 +397,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	    ".Lround%=:\n"                                /* refill, then the next round       */ \
 	    "s_cmp_eq_u64 %[act], 0\n"                                                            \
 	    "s_cbranch_scc1 .Lout%=\n"                                                            \
-	    "s_waitcnt vmcnt(0)\n"                                                                \
+	    "s_waitcnt vmcnt(4)\n"                        /* (in issue order: the piece came before the round's >= 4 stores) */ \
 	    "s_mov_b64 exec, %[req]\n"                    /* the piece asked for a round ago   */ \
 	    "v_and_or_b32 v25, %[fill], %[rmask], %[rbase]\n"                                     \
 	    "ds_write_b64 v25, %[data]\n"                                                         \
@@ -380,9 +421,9 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	    : [cp] "+v"(cp), [nb] "+v"(nb), [lend] "+v"(lend), [lslot] "+v"(lslot), [fill] "+v"(fill),      \
 	      [data] "+v"(data), [act] "=&s"(act_out), [req] "=&s"(req_out), [cur] "=&s"(cur_out),          \
 	      [it] "=&s"(it_out)                                                                            \
-	    : [actin] "s"(uni64(act)), [reqin] "s"(uni64(req)), [curin] "s"(uni32(log_a + 2 * log.cur)), [itin] "s"(uni32(it)), \
+	    : [actin] "s"(uni64(act)), [reqin] "s"(uni64(req)), [curin] "s"(uni32(log.cur)), [itin] "s"(uni32(it)), [sbase] "s"(uni64((unsigned long long)(uintptr_t)log.base)), \
 	      [hi] "v"(end), [rbase] "v"(ring_a), [tb] "v"(tb), [rmask] "s"(RING - 1), [basea] "s"(label_bytes), \
-	      [high] "s"(log_a + 2 * HIGH), [room] "s"(RING - 8), [km1] "s"(round - 1), [tprep] "s"(W.tprep)           \
+	      [high] "s"(HIGH), [room] "s"(RING - 8), [km1] "s"(round - 1), [tprep] "s"(W.tprep)           \
 	    : "v24", "v25", "v26", "v27", "v28", "v29", "s38", "s39", "s40", "s41", "s42", "s43", "vcc", "scc", "memory")
 
 template <uint32_t RING, bool ASM>
@@ -412,10 +453,10 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 		return;
 	}
 	// (ring bases are multiples of the ring size: the assembly ORs a ring offset into them)
-	LDS_AS unsigned char *wbase = lds + ((label_bytes + info_bytes + 127) & ~127u) + wave * (64 * RING + kLogEntries * 2);
+	LDS_AS unsigned char *wbase = lds + ((label_bytes + info_bytes + 127) & ~127u) + wave * (64 * RING);
 	LDS_AS unsigned char *ring = wbase + lane * RING;
-	WaveLog log;
-	log.init((LDS_AS uint16_t *)(wbase + 64 * RING), lane);
+	DirectLog log;
+	log.open(Qd, lane);
 
 	const uint32_t total_waves = gridDim.x * waves;
 	const uint32_t rows = W.range_bytes + W.halo; // bytes a lane's range has in its block (multiple of 8)
@@ -445,7 +486,6 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 		wave_fence();
 		if constexpr (ASM) {
 			const uint32_t ring_a = (uint32_t)(uintptr_t)ring;
-			const uint32_t log_a = uni32((uint32_t)(uintptr_t)log.cells);
 			const uint32_t tb = (uint32_t)((size_t)wb * rows * 64 + lane * 8); // (the transposed copy is below 4 GiB)
 			unsigned long long act = __builtin_amdgcn_ballot_w64(active), req = 0;
 			u32x2 data = {0, 0};
@@ -453,10 +493,10 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 			while (act != 0) {
 				unsigned long long act_out, req_out;
 				uint32_t cur_out, it_out;
-				TOK_RANGES_ASM(kLogHigh);
+				TOK_RANGES_ASM(DirectLog::kHighBytes);
 				act = act_out, req = req_out, it = it_out;
-				log.cur = (cur_out - log_a) / 2;
-				if (log.cur > kLogHigh) log.flush(Qd, lane);
+				log.cur = cur_out;
+				log.roll_if_full(Qd, lane);
 			}
 		} else {
 			bool req = false;
@@ -488,7 +528,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 					}
 					log.put(done, lslot);
 					if (done) active = cp < end; // (nb is 0 = the root again)
-					if (log.cur > kLogHigh) log.flush(Qd, lane);
+					log.roll_if_full(Qd, lane);
 					act = __builtin_amdgcn_ballot_w64(active);
 					if (act == 0) break;
 				}
@@ -496,7 +536,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 		}
 		if (g < W.nranges) W.exit_a[g] = cp - end;
 	}
-	log.finish(Qd, lane);
+	log.close(Qd, lane);
 }
 
 // tprep block wb, piece k, lane l = the 8 bytes prep[(wb * 64 + l) * range_bytes + 8 k ...] (zero past
@@ -658,16 +698,26 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 	const uint32_t sgn = flip ? 0xFFFFFFFFu : 1u;
 	uint32_t seen = 0;
 	for (uint32_t bt = wave_id; bt < batches; bt += n_waves) {
-		uint32_t live = Qd.fill[bt];
-		if (live > kStreamBatch) live = kStreamBatch;
-		const uint32_t live_rows = uni32(live);
+		uint32_t live = Qd.fill[bt]; // entries written to the batch (what follows them was never written)
+		if (live > kBatchEntries) live = kBatchEntries;
+		live = uni32(live);
+		const uint32_t live_rows = (live + 511) / 512;
 		const uint4 *rows = vec + (uint64_t)bt * kStreamBatch * vecs_per_block + lane;
 		for (uint32_t r0 = 0; r0 < live_rows; r0 += kRowsInFlight) {
 			uint4 v[kRowsInFlight];
 #pragma unroll
 			for (int u = 0; u < kRowsInFlight; u++) {
 				v[u] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-				if (r0 + u < live_rows) v[u] = rows[(size_t)(r0 + u) * 64];
+				if (r0 + u < live_rows) {
+					v[u] = rows[(size_t)(r0 + u) * 64];
+					const uint32_t first = (r0 + u) * 512 + lane * 8; // this lane's eight entries of the row
+					if (first + 8 > live) { // the batch's last, partly written vector: blank what lies past `live`
+						uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+						for (uint32_t q = 0; q < 8; q++)
+							if (first + q >= live) w[q >> 1] |= 0xFFFFu << (16 * (q & 1));
+						v[u] = uint4{w[0], w[1], w[2], w[3]};
+					}
+				}
 			}
 #pragma unroll
 			for (int u = 0; u < kRowsInFlight; u++) {
@@ -779,7 +829,7 @@ bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, Strea
 	}
 	const uint32_t label_bytes = (nslots + 15) & ~15u;
 	const uint32_t info_bytes = (nslots * 2 + 15) & ~15u;
-	const uint32_t wave_bytes = 64 * ring + kLogEntries * 2;
+	const uint32_t wave_bytes = 64 * ring;
 	const uint32_t lds_total = 160 * 1024 - 64;
 	const uint32_t image_bytes = (label_bytes + info_bytes + 127) & ~127u;
 	if (image_bytes + 4 * wave_bytes > lds_total) return false;

@@ -26,12 +26,13 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+    kernel = json.loads(line).get("roofline", {}).get("kernel", "scan_tile_kernel")
     pmc = {}
     for f in sorted(glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
         acc = collections.defaultdict(float)
         disp = collections.defaultdict(set)
         for r in csv.DictReader(open(f)):
-            if "scan_tile" in r["Kernel_Name"]:
+            if kernel in r["Kernel_Name"]:
                 acc[r["Counter_Name"]] += float(r["Counter_Value"])
                 disp[r["Counter_Name"]].add(r["Dispatch_Id"])
         for k in acc:
@@ -40,7 +41,7 @@ def main():
         pmc["hbm_read_bytes_per_launch"] = 2 * pmc["FETCH_SIZE"] * 1024   # gfx950: FETCH_SIZE counts 128-B requests as 64 B
         pmc["hbm_write_bytes_per_launch"] = pmc["WRITE_SIZE"] * 1024
         pmc["traffic_bytes_per_launch"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
-    pmc["kernel"] = "scan_tile_kernel"
+    pmc["kernel"] = kernel
     json.dump(pmc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(pmc, indent=1, sort_keys=True))
 
