@@ -367,17 +367,18 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	    "v_add_u32 v29, 1, %[cp]\n"                                                           \
 	    "s_waitcnt lgkmcnt(0)\n"                                                              \
 	    "v_xor_b32 v27, v27, v24\n"                   /* 0x80 hit on a token end, 0 hit    */ \
-	    "v_cmp_eq_u32 vcc, 0x80, v27\n"                                                       \
-	    "v_cndmask_b32 %[lend], %[lend], v29, vcc\n"                                          \
-	    "v_cndmask_b32 %[lslot], %[lslot], v25, vcc\n"                                        \
-	    "v_and_b32 v27, 0x7f, v27\n"                                                          \
-	    "v_cmp_eq_u32 vcc, 0, v27\n"                                                          \
-	    "v_cndmask_b32 %[nb], 0, v28, vcc\n"          /* miss or leaf: 0 = the root again  */ \
-	    "v_cmp_ne_u32 vcc, 0, %[nb]\n"                                                        \
-	    "v_cndmask_b32 %[cp], %[lend], v29, vcc\n"    /* goes on, or next token's start    */ \
+	    "v_cmp_ne_u32 s[42:43], 0, v28\n"             /* the slot has children             */ \
+	    "v_cmp_eq_u32 s[40:41], %[k80], v27\n"        /* token end                         */ \
+	    "v_and_b32 v26, 0x7f, v27\n"                                                          \
+	    "v_cmp_eq_u32 vcc, 0, v26\n"                  /* hit                               */ \
+	    "v_cndmask_b32 %[lend], %[lend], v29, s[40:41]\n" /* (gfx950: two states between a VALU's mask and the VALU reading it) */ \
+	    "v_cndmask_b32 %[lslot], %[lslot], v25, s[40:41]\n"                                   \
+	    "s_and_b64 s[40:41], vcc, s[42:43]\n"         /* the token goes on                 */ \
+	    "v_cndmask_b32 %[cp], %[lend], v29, s[40:41]\n" /* ... or the next token starts at lend */ \
+	    "v_cndmask_b32 %[nb], 0, v28, s[40:41]\n"     /* token complete: 0 = the root again */ \
 	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
 	    "ds_read_u8 v24, v25\n"                                                               \
-	    "s_andn2_b64 s[42:43], exec, vcc\n"           /* lanes whose token is complete     */ \
+	    "s_andn2_b64 s[42:43], exec, s[40:41]\n"      /* lanes whose token is complete     */ \
 	    "s_mov_b64 exec, s[42:43]\n"                                                          \
 	    "v_mbcnt_lo_u32_b32 v26, s42, 0\n"                                                    \
 	    "v_mbcnt_hi_u32_b32 v26, s43, v26\n"          /* rank among them                   */ \
@@ -411,8 +412,6 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	    "s_waitcnt lgkmcnt(0)\n"                      /* (data is free again)              */ \
 	    "global_load_dwordx2 %[data], v25, %[tprep]\n"                                        \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
-	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
-	    "ds_read_u8 v24, v25\n"                                                               \
 	    "s_mov_b32 %[it], %[km1]\n"                                                           \
 	    "s_branch .Lcheck%=\n"                                                                \
 	    ".Lout%=:\n"                                                                          \
@@ -423,7 +422,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	      [it] "=&s"(it_out)                                                                            \
 	    : [actin] "s"(uni64(act)), [reqin] "s"(uni64(req)), [curin] "s"(uni32(log.cur)), [itin] "s"(uni32(it)), [sbase] "s"(uni64((unsigned long long)(uintptr_t)log.base)), \
 	      [hi] "v"(end), [rbase] "v"(ring_a), [tb] "v"(tb), [rmask] "s"(RING - 1), [basea] "s"(label_bytes), \
-	      [high] "s"(HIGH), [room] "s"(RING - 8), [km1] "s"(round - 1), [tprep] "s"(W.tprep)           \
+	      [high] "s"(HIGH), [k80] "s"(0x80u), [room] "s"(RING - 8), [km1] "s"(round - 1), [tprep] "s"(W.tprep)           \
 	    : "v24", "v25", "v26", "v27", "v28", "v29", "s38", "s39", "s40", "s41", "s42", "s43", "vcc", "scc", "memory")
 
 template <uint32_t RING, bool ASM>
