@@ -360,6 +360,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	    "s_cbranch_scc1 .Lround%=\n"                                                          \
 	    ".Ltop%=:\n"                                                                          \
 	    "s_waitcnt lgkmcnt(0)\n"                                                              \
+	    "s_setprio 2\n"                               /* the dependent part of a lookup goes before other waves' logging */ \
 	    "v_add_u32 v25, %[nb], v24\n"                 /* slot t = LDS address of lt[t]     */ \
 	    "v_lshl_add_u32 v26, v25, 1, %[basea]\n"      /* address of base[t]                */ \
 	    "ds_read_u8 v27, v25\n"                                                               \
@@ -378,6 +379,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	    "v_cndmask_b32 %[nb], 0, v28, s[40:41]\n"     /* token complete: 0 = the root again */ \
 	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
 	    "ds_read_u8 v24, v25\n"                                                               \
+	    "s_setprio 0\n"                                                                       \
 	    "s_andn2_b64 s[42:43], exec, s[40:41]\n"      /* lanes whose token is complete     */ \
 	    "s_mov_b64 exec, s[42:43]\n"                                                          \
 	    "v_mbcnt_lo_u32_b32 v26, s42, 0\n"                                                    \
