@@ -12,6 +12,10 @@ besides the count all-reduce).
     python bench.py [--gpus N --steps K --warmup W] [--mb 100] [--vocab 32000]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself -- a child
+`python -m torch.distributed.run`, before anything here touches the GPU -- and refuses loudly when
+fewer than N devices are visible.  `--mb 2500` is configs[2]'s per-GPU share (20 GB over 8 GPUs).
+
 Prints one JSON line on rank 0.  The CPU oracle / compiled reference is timed beside it
 (cpu_baseline) on a bounded sample; it is never part of the measured GPU path.
 """
@@ -43,6 +47,7 @@ def cpu_baseline(corpus, off, tokens, sample_bytes=100_000_000):  # the whole be
     nbytes = int(sub_off[-1])
     cores = min(16, os.cpu_count() or 1)  # the GPU box grants 16 host cores per GPU
     out = {}
+    ref_result = None
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     if os.path.exists(harness):
         with tempfile.TemporaryDirectory() as tmp:
@@ -56,20 +61,101 @@ def cpu_baseline(corpus, off, tokens, sample_bytes=100_000_000):  # the whole be
                             os.path.join(tmp, "e.json"), "--threads", str(cores)], check=True,
                            stdout=subprocess.DEVNULL)
             e = json.load(open(os.path.join(tmp, "e.json")))
+        ref_result = e
         out = {"value": nbytes / e["tokenize_seconds"] / 1e9, "unit": "GB/s", "cores": cores, "kind": "reference",
                "sample": "first %d documents (%d bytes) of the rank-0 shard, compiled reference "
                          "SolutionFile::Tokenize on %d threads, Tokenize time only" % (d_end, nbytes, cores)}
     import oracle_ffi as O
     voc = O.OracleVocab(*synth.pack_vocab(tokens))
     t0 = time.time()
-    voc.score(corpus[:nbytes], sub_off, threads=cores)
+    oracle_result = voc.score(corpus[:nbytes], sub_off, threads=cores)
     port = nbytes / (time.time() - t0) / 1e9
     if not out:
         out = {"value": port, "unit": "GB/s", "cores": cores, "kind": "port",
                "sample": "first %d documents (%d bytes) of the rank-0 shard, oracle/tokscore_oracle.c on %d threads"
                          % (d_end, nbytes, cores)}
     out["port_value"] = port
+    return out, {"bytes": nbytes, "docs": d_end, "oracle": oracle_result, "reference": ref_result}
+
+
+def parity_check(gpu_vec, V, total_bytes, checked):
+    """configs[1]'s "bit-exact count check", in the run: the GPU's counts | total_tokens |
+    total_bytes for the whole shard against what the CPU side of cpu_baseline produced for the same
+    bytes -- the compiled reference (oracle/_ref, main.cpp:38-45 over SolutionFile::Tokenize) when
+    present, and the C restatement.  Only when the CPU sample was the whole shard."""
+    if checked["bytes"] != total_bytes:
+        return {"against": None, "bytes": checked["bytes"], "exact": None,
+                "note": "the CPU sample is not the whole shard: nothing to compare"}
+    counts, tt, tb = checked["oracle"]
+    exact = bool(np.array_equal(gpu_vec[:V + 3], counts)) and int(gpu_vec[V + 3]) == int(tt) and int(gpu_vec[V + 4]) == int(tb)
+    against = "oracle"
+    ref = checked["reference"]
+    if ref is not None:
+        rc = np.zeros(V + 3, dtype=np.uint64)
+        for k, v in ref["counts"].items():
+            rc[V + 2 if int(k) < 0 else int(k)] = v
+        exact = exact and bool(np.array_equal(gpu_vec[:V + 3], rc)) and int(gpu_vec[V + 3]) == int(ref["total_tokens"]) \
+            and int(gpu_vec[V + 4]) == int(ref["total_bytes"])
+        against = "reference"
+    return {"against": against, "bytes": checked["bytes"], "docs": checked["docs"], "exact": exact}
+
+
+# ---- the step and its reduction: what tests/test_sharding_gloo.py drives on CPU with gloo ----
+
+def reduce_result(out, dist, world, host_reduce=False):
+    """The one exchange of the path: in-place SUM all-reduce of counts | total_tokens | total_bytes
+    (int64 view of the u64 words: wrap-around addition).  host_reduce: through a host copy (gloo)."""
+    if world <= 1:
+        return out
+    if host_reduce:
+        host_copy = out.cpu()
+        dist.all_reduce(host_copy)
+        out.copy_(host_copy)
+    else:
+        dist.all_reduce(out)
     return out
+
+
+def timed_steps(step, fence, steps, warmup, after_warmup=None):
+    """W untimed steps, then exactly K steps between two fences; seconds of the K steps."""
+    for _ in range(warmup):
+        step()
+    fence()
+    if after_warmup:
+        after_warmup()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(elapsed, dist, world, device):
+    import torch
+    if world <= 1:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: start the N ranks (one per GPU, RCCL) as a child process, before
+    this process has touched a GPU; its exit code is ours."""
+    import torch  # (device_count does not initialise the GPU)
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible: refusing to run fewer ranks under that label\n"
+                         % (args.gpus, have))
+        return 2
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def measured_traffic(workload_bytes):
@@ -175,6 +261,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("BENCH_REHEARSAL") != "1":
+        sys.exit(launch_ranks(args))
+
     import torch
     import tokenizer_amd as ta
     from tokenizer_amd import synth
@@ -185,8 +274,15 @@ def main():
     # BENCH_REHEARSAL=1: all ranks on GPU 0 over gloo -- exercises the N > 1 code path on a
     # one-GPU box (RCCL refuses two ranks on one device); never used for a reported number.
     rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d rank(s)\n" % (args.gpus, world))
+        sys.exit(2)
     if rehearsal:
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: rank %d has no GPU (%d visible)\n" % (rank, torch.cuda.device_count()))
+        sys.exit(2)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         if rehearsal:
@@ -212,15 +308,11 @@ def main():
     out = torch.zeros(V + 5, dtype=torch.int64, device=dev)  # counts | total_tokens | total_bytes
     stream = torch.cuda.current_stream()
 
+    dist_mod = dist if world > 1 else None
+
     def step():
         scorer.score_async(out.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            if rehearsal:  # gloo: reduce a host copy
-                host_copy = out.cpu()
-                dist.all_reduce(host_copy)
-                out.copy_(host_copy)
-            else:
-                dist.all_reduce(out)
+        reduce_result(out, dist_mod, world, host_reduce=rehearsal)
 
     def fence():
         torch.cuda.synchronize()
@@ -228,27 +320,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    scorer.drain_timings()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(step, fence, args.steps, args.warmup, after_warmup=scorer.drain_timings)
     # HIP events the library recorded around its kernels, on the stream they ran on,
     # for exactly the K timed steps (read after the region: no host sync inside it)
     tm = scorer.drain_timings()[-args.steps:]
     eval_ms = [t[0] for t in tm]
     scan_ms = [t[1] for t in tm]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, dist_mod, world, "cpu" if rehearsal else dev)
+    # what d_out cannot show: a token-stream overflow of the last asynchronous evaluation
+    overflowed = scorer.async_status(stream.cuda_stream)
+    if overflowed:
+        sys.stderr.write("bench.py: rank %d: the asynchronous evaluation overflowed its token stream; result invalid\n" % rank)
+        sys.exit(3)
 
     host = out.cpu().numpy().view(np.uint64)
     total_bytes_all = int(host[V + 4])  # after the all-reduce: all ranks' bytes
+    if world == 1:
+        local_vec = host.copy()
+    else:  # this rank's own evaluation, for the parity check (the all-reduced vector is the sum over ranks)
+        scorer.score_async(out.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        local_vec = out.cpu().numpy().view(np.uint64).copy()
     info = scorer.info()
     if rank == 0:
         value = total_bytes_all * args.steps / elapsed / 1e9
@@ -282,9 +374,14 @@ def main():
         }
         if world == 1 and not args.no_cpu:
             rec["two_evaluations_in_flight"] = two_in_flight(scorer, tokens, corpus, off, dev, args.steps)
-            rec["cpu_baseline"] = cpu_baseline(corpus, off, tokens)
+            rec["cpu_baseline"], checked = cpu_baseline(corpus, off, tokens)
+            rec["parity_checked"] = parity_check(local_vec, V, int(info.corpus_bytes), checked)
             rec["annealing_moves_per_s"] = moves_per_sec(scorer, tokens, corpus, off)
         print(json.dumps(rec))
+        if rec.get("parity_checked", {}).get("exact") is False:
+            sys.stderr.write("bench.py: the GPU result differs from the CPU %s on the bench shard\n" % rec["parity_checked"]["against"])
+            scorer.close()
+            sys.exit(4)
     scorer.close()
     if world > 1:
         dist.destroy_process_group()

@@ -106,6 +106,15 @@ int tokscore_score(tokscore_ctx *ctx, uint64_t *counts, uint64_t *total_tokens, 
  * enqueued on `stream` (a hipStream_t, or NULL for the context's own stream). */
 int tokscore_score_async(tokscore_ctx *ctx, void *d_out, void *stream);
 
+/* What an asynchronous caller cannot see in d_out: waits for `stream` (NULL: the context's own),
+ * then *overflowed = 1 when the last tokscore_score_async enqueued there ran out of its internal
+ * token-stream capacity -- d_out is then incomplete and the evaluation has to be redone with
+ * tokscore_score, which falls back by itself (the reference has no capacity to exceed,
+ * src/files/SolutionFile.cpp:84-99 grows a vector; the stream scan's capacity is a true upper
+ * bound, so only the tile scan on adversarial input can report 1).  One context = one evaluation
+ * in flight on one stream: the scratch buffers of an evaluation belong to the context. */
+int tokscore_async_status(tokscore_ctx *ctx, void *stream, int *overflowed);
+
 /* Re-score after tokscore_toggle calls: identical results to tokscore_score, bit for bit.
  * Only the work chunks that contain a toggled entry's string are scanned again (with the
  * trie as it was: subtracted; as it is: added) on top of the previous evaluation's counts,

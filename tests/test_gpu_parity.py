@@ -299,3 +299,73 @@ def test_incremental_rescore_paths(index_mb, path):
             os.environ.pop("TOKSCORE_INDEX_MB", None)
         else:
             os.environ["TOKSCORE_INDEX_MB"] = old_env
+
+
+class _DeviceBuffer:
+    """A device buffer without torch (whose bundled HIP runtime must not be loaded second into a
+    process that already runs libtokscore.so's): hipMalloc / hipMemcpy through ctypes."""
+
+    def __init__(self, nbytes):
+        import ctypes as C
+        self.C = C
+        self.hip = C.CDLL("libamdhip64.so")
+        self.ptr = C.c_void_p()
+        self.nbytes = nbytes
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(nbytes)) == 0
+
+    def to_host(self):
+        host = np.zeros(self.nbytes // 8, dtype=np.uint64)
+        assert self.hip.hipMemcpy(host.ctypes.data_as(self.C.c_void_p), self.ptr, self.C.c_size_t(self.nbytes), 2) == 0  # D2H
+        return host
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
+def test_stream_overflow_is_reported_or_rescued():
+    """The tile scan's token stream has a capacity (the stream scan's cannot be exceeded).  With the
+    capacity shrunk (TOKSCORE_STREAM_DIV) the periodic golden overflows it: the synchronous call
+    must redo the evaluation on the generic path and still be exact, the asynchronous one must
+    raise the flag tokscore_async_status reads -- never a silently short result."""
+    g = O.load_golden("periodic")
+    corpus, off = synth.pack_docs(g["docs"])
+    exp = g["expected"]
+    V = len(g["tokens"])
+    s, old = _scorer({"TOKSCORE_SCAN": "tile", "TOKSCORE_STREAM_DIV": "4000"})
+    out = None
+    try:
+        s.set_vocab(*synth.pack_vocab(g["tokens"]))
+        s.set_corpus(corpus, off)
+        out = _DeviceBuffer((V + 5) * 8)
+        s.score_async(out.ptr.value)  # on the context's own stream
+        assert s.info().scan_path == 1
+        assert s.async_status() is True, "an overflowed asynchronous evaluation must say so"
+        counts, tt, tb = s.score()  # falls back by itself
+        assert s.info().scan_path == 0
+        assert (tt, tb) == (exp["total_tokens"], exp["total_bytes"])
+        assert np.array_equal(counts, exp["counts_vec"])
+        s.score_async(out.ptr.value)
+        assert s.async_status() is False
+        got = out.to_host()
+        assert np.array_equal(got[:V + 3], exp["counts_vec"]) and int(got[V + 3]) == exp["total_tokens"]
+    finally:
+        _restore(old)
+        s.close()
+        if out:
+            out.free()
+    # the stream scan on the same input: no capacity to exceed
+    s, old = _scorer({"TOKSCORE_SCAN": "stream", "TOKSCORE_STREAM_DIV": "4000"})
+    out = None
+    try:
+        s.set_vocab(*synth.pack_vocab(g["tokens"]))
+        s.set_corpus(corpus, off)
+        out = _DeviceBuffer((V + 5) * 8)
+        s.score_async(out.ptr.value)
+        assert s.async_status() is False
+        got = out.to_host()
+        assert np.array_equal(got[:V + 3], exp["counts_vec"])
+    finally:
+        _restore(old)
+        s.close()
+        if out:
+            out.free()

@@ -11,6 +11,9 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+import subprocess
+import sys
+
 import oracle_ffi as O
 from tokenizer_amd import annealing as A
 from tokenizer_amd import shard, synth
@@ -30,10 +33,21 @@ def _worker(rank, world, port, tokens, corpus, off, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c, o = shard.shard_corpus(corpus, off, rank, world)
     voc = O.OracleVocab(*synth.pack_vocab(tokens))
-    counts, tt, tb = voc.score(c, o)
-    vec = np.concatenate([counts, np.array([tt, tb], dtype=np.uint64)])
-    t = torch.from_numpy(vec.view(np.int64).copy())
-    shard.all_reduce_counts(t, dist)
+    import bench  # the step, the reduction and the timing loop are bench.py's own code, not a copy of it
+    t = torch.zeros(len(tokens) + 5, dtype=torch.int64)
+    calls = []
+
+    def step():  # bench.py's step with the CPU oracle standing in for score_async (no GPU here)
+        counts, tt, tb = voc.score(c, o)
+        vec = np.concatenate([counts, np.array([tt, tb], dtype=np.uint64)])
+        t.copy_(torch.from_numpy(vec.view(np.int64).copy()))
+        bench.reduce_result(t, dist, world, host_reduce=True)
+        calls.append(1)
+
+    elapsed = bench.timed_steps(step, dist.barrier, steps=2, warmup=1)
+    assert len(calls) == 3 and elapsed > 0
+    slowest = bench.max_over_ranks(elapsed, dist, world, "cpu")
+    assert slowest >= elapsed
     if rank == 0:
         q.put(t.numpy().view(np.uint64).copy())
     dist.barrier()
@@ -108,3 +122,16 @@ def test_candidates_merged_up_the_rank_tree_equal_one_extraction(world):
         assert p.exitcode == 0
     for a, b in zip(got, expect):
         assert np.array_equal(a, b)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`bench.py --gpus N` starts N ranks by itself; with fewer than N GPUs visible it must fail
+    loudly, never run fewer ranks and print a line that says n_gpus = 1."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-400:])
+    assert "refusing" in r.stderr and "n_gpus" not in r.stdout

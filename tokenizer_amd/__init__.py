@@ -47,6 +47,7 @@ _SIGNATURES = [
     ("tokscore_set_corpus_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
     ("tokscore_score", C.c_int, [C.c_void_p, _u64p, _u64p, _u64p]),
     ("tokscore_score_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("tokscore_async_status", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     ("tokscore_score_incremental", C.c_int, [C.c_void_p, _u64p, _u64p, _u64p]),
     ("tokscore_count_occurrences", C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
     ("tokscore_extract_candidates", C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
@@ -174,6 +175,13 @@ class Scorer:
 
     def score_async(self, d_out_ptr: int, stream_ptr: int = 0):
         self._check(self._lib.tokscore_score_async(self._h, d_out_ptr, stream_ptr))
+
+    def async_status(self, stream_ptr: int = 0) -> bool:
+        """Waits for the stream; True when the last score_async there overflowed its token stream
+        (its d_out is incomplete: redo with score(), which falls back by itself)."""
+        flag = C.c_int(0)
+        self._check(self._lib.tokscore_async_status(self._h, stream_ptr, C.byref(flag)))
+        return bool(flag.value)
 
     # ExtractCandidates + Trie::AddString on a closed vocabulary (GetTokens.cpp:21-27, Trie.cpp:114-128)
     def count_occurrences(self, max_cp: int):

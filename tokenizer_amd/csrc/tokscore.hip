@@ -671,7 +671,9 @@ int ensure_plan(tokscore_ctx *c) {
 		const uint64_t entry_bytes = c->tile.wide_ids ? 4 : 2;
 		const uint64_t block_bytes = stream_block_bytes(c->tile.wide_ids);
 		const uint64_t waves = (uint64_t)c->tile.blocks * c->tile.waves_per_block;
-		const uint64_t batches = (3 * c->total * entry_bytes) / (block_bytes * kStreamBatch) + 2 * waves + 16;
+		// (TOKSCORE_STREAM_DIV: tests shrink the capacity to exercise the overflow report and the fallback)
+		const uint64_t batches = (3 * c->total * entry_bytes) / (block_bytes * kStreamBatch) / std::max<uint64_t>(1, env_u64("TOKSCORE_STREAM_DIV", 1)) +
+		                         (env_u64("TOKSCORE_STREAM_DIV", 1) > 1 ? 1 : 2 * waves + 16);
 		if (batches > 0x7FFFFFF0ull) return fail(c, TOKSCORE_E_CAPACITY, "corpus too large for one token stream");
 		c->stream_cap_batches = (uint32_t)batches;
 		HIP_TRY(c, hipMalloc(&c->d_stream, batches * kStreamBatch * block_bytes));
@@ -1071,6 +1073,19 @@ int tokscore_score_async(tokscore_ctx *c, void *d_out, void *stream) {
 	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
 	(void)hipSetDevice(c->device);
 	return enqueue_score(c, (unsigned long long *)d_out, stream ? (hipStream_t)stream : c->stream);
+}
+
+int tokscore_async_status(tokscore_ctx *c, void *stream, int *overflowed) {
+	if (!c || !overflowed) return fail(c, TOKSCORE_E_ARG, "null output");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	uint32_t words[2] = {0, 0};
+	if (c->plan_valid && c->scan_path >= 1 && c->d_cursor)
+		HIP_TRY(c, hipMemcpyAsync(words, c->d_cursor, sizeof words, hipMemcpyDeviceToHost, s));
+	HIP_TRY(c, hipStreamSynchronize(s));
+	*overflowed = words[1] != 0;
+	return TOKSCORE_OK;
 }
 
 int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, uint64_t *total_bytes) {
