@@ -575,7 +575,8 @@ struct FixDev {
 	const uint8_t *prep;
 	uint32_t prep_total, range_bytes, nranges;
 	uint32_t *entry, *exit_a, *exit_b;
-	uint32_t *changed; // set when some repair moved an exit
+	uint32_t *changed; // [0] set when some repair moved an exit, [1] workgroups done
+	uint32_t epoch;    // 1 .. 65535, another one every evaluation: exit_b[g] counts only when tagged with it
 	unsigned long long *out;
 	uint32_t total_index;
 };
@@ -623,9 +624,15 @@ __device__ bool dual_walk_image(const FixDev &F, uint32_t end, uint32_t pa, uint
 	return pa == pb;
 }
 
+__device__ void fixup_ordered_pass(const FixDev &F);
+
 __global__ void __launch_bounds__(256) fixup_parallel_stream_kernel(FixDev F) {
+	__shared__ uint32_t s_last, s_wrote;
+	if (threadIdx.x == 0) s_wrote = 0;
+	__syncthreads();
 	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < F.nranges; g += gridDim.x * blockDim.x) {
 		uint32_t ex = F.exit_a[g];
+		(void)ex;
 		if (g > 0) {
 			const uint32_t want = F.exit_a[g - 1];
 			const uint32_t have = F.entry[g];
@@ -635,23 +642,45 @@ __global__ void __launch_bounds__(256) fixup_parallel_stream_kernel(FixDev F) {
 				uint32_t pa;
 				if (!dual_walk_image(F, end, begin + want, begin + have, &pa)) {
 					ex = pa - end;
-					F.changed[0] = 1u;
+					atomicOr(&F.changed[0], 1u);
 				}
 				F.entry[g] = want;
+				F.exit_b[g] = F.epoch << 16 | ex; // (an overshoot is shorter than a token: 16 bits)
+				s_wrote = 1u;
 			}
 		}
-		F.exit_b[g] = ex;
 	}
+	// The ordered pass (rare: only when a repair moved an exit) is done by whichever workgroup
+	// finishes last, in the same launch: a launch of its own costs more than a normal evaluation's
+	// whole fix-up.  changed[1] counts the workgroups that are done.
+	// (a fence costs microseconds: only a workgroup that repaired something has anything to publish,
+	// and exit_b is only read by the ordered pass, which runs only after some repair)
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		if (s_wrote) __threadfence();
+		s_last = atomicAdd(&F.changed[1], 1u) == gridDim.x - 1 ? 1u : 0u;
+	}
+	__syncthreads();
+	if (!s_last) return;
+	fixup_ordered_pass(F);
 }
 
-// ONE block; every thread reaches every barrier.  Does nothing unless a repair moved an exit.
-__global__ void __launch_bounds__(1024) fixup_ordered_stream_kernel(FixDev F) {
+// ONE workgroup; every thread reaches every barrier.  Does nothing unless a repair moved an exit.
+// exit of range g after the repairs so far: exit_b where this evaluation wrote one (published by
+// the writer's fence), else what the scan left
+__device__ __forceinline__ uint32_t exit_now(const FixDev &F, uint32_t g) {
+	const uint32_t b = F.exit_b[g];
+	return (b >> 16) == F.epoch ? (b & 0xFFFFu) : F.exit_a[g];
+}
+
+__device__ void fixup_ordered_pass(const FixDev &F) {
 	__shared__ uint32_t s_first;
-	if (F.changed[0] == 0) return; // uniform: written by the kernel before this one
+	if (__hip_atomic_load(&F.changed[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return; // uniform
+	__threadfence(); // the other workgroups' exit_b / entry
 	for (uint32_t base = 1; base < F.nranges; base += blockDim.x) {
 		for (;;) {
 			const uint32_t g = base + threadIdx.x;
-			const bool need = g < F.nranges && F.exit_b[g - 1] != F.entry[g];
+			const bool need = g < F.nranges && exit_now(F, g - 1) != F.entry[g];
 			if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
 			__syncthreads();
 			if (need) atomicMin(&s_first, g);
@@ -659,12 +688,12 @@ __global__ void __launch_bounds__(1024) fixup_ordered_stream_kernel(FixDev F) {
 			const uint32_t first = s_first;
 			if (first == 0xFFFFFFFFu) break;
 			if (g == first) {
-				const uint32_t want = F.exit_b[g - 1];
+				const uint32_t want = exit_now(F, g - 1);
 				const uint32_t have = F.entry[g];
 				const uint32_t begin = g * F.range_bytes;
 				const uint32_t end = begin + F.range_bytes < F.prep_total ? begin + F.range_bytes : F.prep_total;
 				uint32_t pa;
-				if (!dual_walk_image(F, end, begin + want, begin + have, &pa)) F.exit_b[g] = pa - end;
+				if (!dual_walk_image(F, end, begin + want, begin + have, &pa)) F.exit_b[g] = F.epoch << 16 | (pa - end);
 				F.entry[g] = want;
 				__threadfence();
 			}
@@ -751,14 +780,33 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 // Slab rows (int32 partials per slot, column nslots = entries seen) -> out: counts[slot_id[s]] +=
 // column sums; entries on slots nobody counts (document separators) leave the token total again
 // (main.cpp:41 counts the ids Tokenize returned, not the separators this layout adds).
+// One workgroup = 64 columns x 16 row groups: wave w sums the rows r = w, w + 16, ... of its 64
+// columns (256 contiguous bytes per row), the partials meet in LDS, and wave 0 adds each column's
+// total to the id its slot counts for -- one scattered 64-bit atomic per slot and evaluation.
 constexpr uint32_t kMapReduceGroups = 16;
-__global__ void __launch_bounds__(256) slab_reduce_map_kernel(const uint32_t *slab, uint32_t rows, uint32_t nslots,
-                                                              const uint32_t *slot_id, unsigned long long *out,
-                                                              uint32_t total_index) {
-	const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-	if (s > nslots) return;
+__global__ void __launch_bounds__(1024) slab_reduce_map_kernel(const uint32_t *slab, uint32_t rows, uint32_t nslots,
+                                                               const uint32_t *slot_id, unsigned long long *out,
+                                                               uint32_t total_index) {
+	__shared__ long long part[kMapReduceGroups][64];
+	const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+	const uint32_t s = blockIdx.x * 64 + lane;
+	const size_t stride = (size_t)nslots + 1;
 	long long sum = 0;
-	for (uint32_t r = blockIdx.y; r < rows; r += kMapReduceGroups) sum += (long long)(int32_t)slab[(size_t)r * (nslots + 1) + s];
+	if (s <= nslots) {
+		uint32_t r = grp;
+		for (; r + 3 * kMapReduceGroups < rows; r += 4 * kMapReduceGroups) {
+			const int32_t a0 = (int32_t)slab[(size_t)r * stride + s];
+			const int32_t a1 = (int32_t)slab[(size_t)(r + kMapReduceGroups) * stride + s];
+			const int32_t a2 = (int32_t)slab[(size_t)(r + 2 * kMapReduceGroups) * stride + s];
+			const int32_t a3 = (int32_t)slab[(size_t)(r + 3 * kMapReduceGroups) * stride + s];
+			sum += (long long)a0 + a1 + a2 + a3;
+		}
+		for (; r < rows; r += kMapReduceGroups) sum += (long long)(int32_t)slab[(size_t)r * stride + s];
+	}
+	part[grp][lane] = sum;
+	__syncthreads();
+	if (grp != 0 || s > nslots) return;
+	for (uint32_t g = 1; g < kMapReduceGroups; g++) sum += part[g][lane];
 	if (sum == 0) return;
 	if (s == nslots) {
 		atomicAdd(&out[total_index], (unsigned long long)sum);
@@ -893,17 +941,17 @@ void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t 
 	                          (int)lds);
 	hipLaunchKernelGGL(hist_slots_kernel, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, nslots, range, slab,
 	                   flip ? 1u : 0u);
-	hipLaunchKernelGGL(slab_reduce_map_kernel, dim3((nslots + 1 + 255) / 256, kMapReduceGroups), dim3(256), 0, stream, slab,
+	hipLaunchKernelGGL(slab_reduce_map_kernel, dim3((nslots + 1 + 63) / 64), dim3(64 * kMapReduceGroups), 0, stream, slab,
 	                   slab_blocks, nslots, slot_id, out, total_index);
 }
 
 void launch_fixup_stream(const StreamTrieDev &T, const uint32_t *slot_id, const StreamWork &W, uint32_t *exit_b,
-                         uint32_t *changed, unsigned long long *out, uint32_t total_index, hipStream_t stream) {
+                         uint32_t *changed, uint32_t epoch, unsigned long long *out, uint32_t total_index, hipStream_t stream) {
 	if (W.nranges < 2) return;
-	FixDev F{T, slot_id, W.prep, W.prep_total, W.range_bytes, W.nranges, W.entry, W.exit_a, exit_b, changed, out, total_index};
-	const uint32_t blocks = std::min<uint32_t>((W.nranges + 255) / 256, 8192);
+	FixDev F{T, slot_id, W.prep, W.prep_total, W.range_bytes, W.nranges, W.entry, W.exit_a, exit_b, changed, epoch, out, total_index};
+	// (few workgroups: each ends with an atomic on one word, which takes about 10 ns chip-wide)
+	const uint32_t blocks = std::min<uint32_t>((W.nranges + 255) / 256, 64);
 	hipLaunchKernelGGL(fixup_parallel_stream_kernel, dim3(blocks), dim3(256), 0, stream, F);
-	hipLaunchKernelGGL(fixup_ordered_stream_kernel, dim3(1), dim3(1024), 0, stream, F);
 }
 
 uint64_t stream_scan_capacity_batches(uint64_t prep_total, uint32_t waves_total) {

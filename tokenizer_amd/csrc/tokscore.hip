@@ -141,6 +141,7 @@ struct tokscore_ctx {
 	uint32_t range_bytes = 0;        // full evaluation: equal ranges of the prepared corpus, one per lane
 	uint32_t nranges = 0;
 	uint32_t *d_range_state = nullptr; // entry | exit_a | exit_b, nranges words each
+	uint32_t fix_epoch = 0;          // tag of this evaluation's exit_b entries
 	uint8_t *d_tprep = nullptr;      // the ranges transposed, 64 to a block (kernels_stream.hip: scan_ranges_kernel)
 	uint32_t halo = 0;
 	StreamScanPlan rplan = {};       // launch of scan_ranges_kernel
@@ -757,7 +758,8 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		else launch_scan_stream(stream_trie_dev(c), W, Q, c->splan, s);
 		HIP_TRY(c, mark(2));
 		// ranges whose entry was not the previous range's exit (none while the vocabulary stays as it is)
-		launch_fixup_stream(stream_trie_dev(c), c->d_slot_id, W, c->d_range_state + 2 * (size_t)c->nranges, c->d_cursor + 2, d_out,
+		c->fix_epoch = c->fix_epoch % 65535u + 1u;
+		launch_fixup_stream(stream_trie_dev(c), c->d_slot_id, W, c->d_range_state + 2 * (size_t)c->nranges, c->d_cursor + 2, c->fix_epoch, d_out,
 		                    (uint32_t)c->V + 3, s);
 		launch_histogram_slots(Q, (uint32_t)c->simg.lt.size(), c->d_slot_id, d_out, (uint32_t)c->V + 3, c->d_slab,
 		                       c->slab_blocks, s);
