@@ -137,6 +137,21 @@ int tokscore_score_incremental(tokscore_ctx *ctx, uint64_t *counts, uint64_t *to
  *   positions     number of code-point positions (the trie root's freq, Trie.cpp:117) */
 int tokscore_count_occurrences(tokscore_ctx *ctx, uint32_t max_cp, uint64_t *counts, uint64_t *positions);
 
+/* tokscore_count_occurrences for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the
+ * reference.  Same counts, bit for bit, left in device memory: d_out[V+4] = counts[V+3] | positions
+ * (uint64), enqueued on `stream` (a hipStream_t, or NULL for the context's own); the call does not
+ * wait.  It calls no hipMalloc / hipFree: the kernels' scratch (tile queue heads, the first
+ * document of every 1 KiB tile, one row of V+4 partial counts per workgroup) lives in a 16 MiB
+ * array in the library's device image, one copy per GPU, held until the process ends.
+ *   - TOKSCORE_E_CAPACITY when 8 bytes per KiB of corpus plus one row (4 * (V + 4) bytes) exceed
+ *     the 16 MiB; fewer rows than tokscore_count_occurrences would take only make it slower.
+ *   - TOKSCORE_E_STATE until the context has run one evaluation (tokscore_count_occurrences or
+ *     tokscore_score*): copying the trie to the device is set-up and allocates.
+ *   - Every call on a GPU, from any context, shares that GPU's array: two calls that overlap on
+ *     one GPU (two streams, two contexts, two threads) race.  Calls on one stream are ordered. */
+int tokscore_count_occurrences_static(tokscore_ctx *ctx, uint32_t max_cp, void *d_out, void *stream);
+
 /* Open-vocabulary candidate extraction: the candidate set
  * annealing::GetTokens builds from the corpus -- FileCandidates + Trie::BuildTokens
  * (src/tokenizer/GetTokens.cpp:21-90, src/tokenizer/Trie.cpp:81-152) -- for the resident

@@ -50,6 +50,7 @@ _SIGNATURES = [
     ("tokscore_async_status", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     ("tokscore_score_incremental", C.c_int, [C.c_void_p, _u64p, _u64p, _u64p]),
     ("tokscore_count_occurrences", C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
+    ("tokscore_count_occurrences_static", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("tokscore_extract_candidates", C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
     ("tokscore_candidates_copy", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), _u64p, C.POINTER(C.c_uint32),
                                            C.POINTER(C.c_uint32)]),
@@ -191,6 +192,12 @@ class Scorer:
         pos = C.c_uint64()
         self._check(self._lib.tokscore_count_occurrences(self._h, max_cp, _p64(counts), C.byref(pos)))
         return counts, int(pos.value)
+
+    def count_occurrences_static(self, max_cp: int, d_out_ptr: int, stream_ptr: int = 0) -> None:
+        """count_occurrences without any device allocation: d_out_ptr is device memory for V+4 uint64
+        (counts[V+3] | positions); enqueued on stream_ptr (0: the context's stream), not waited for.
+        Scratch is a 16 MiB array inside the library, shared by every call on the GPU."""
+        self._check(self._lib.tokscore_count_occurrences_static(self._h, max_cp, d_out_ptr, stream_ptr))
 
     # GetTokens: FileCandidates + Trie::BuildTokens (GetTokens.cpp:21-90, Trie.cpp:81-152), on the GPU
     def extract_candidates(self, max_cp: int):

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -39,11 +40,39 @@ hipError_t elapsed_ms(float *ms, hipEvent_t a, hipEvent_t b) {
 	return hipEventElapsedTime(ms, a, b);
 }
 
+// ---- scratch of tokscore_count_occurrences_static, the one entry point that allocates nothing.
+// Each GPU the library runs on holds its own copy of the array until the process ends.  In host
+// code the array's name is only a stand-in: the device address of the current GPU's copy comes
+// from hipGetSymbolAddress (once per device, in tokscore_create) and is what every kernel
+// argument and memset below uses.
+constexpr size_t kStaticScratchBytes = (size_t)16 << 20;
+constexpr int kStaticScratchDevices = 64;
+static __device__ __align__(256) unsigned char g_static_scratch[kStaticScratchBytes];
+std::mutex g_static_scratch_mu;
+unsigned char *g_static_scratch_ptr[kStaticScratchDevices]; // by HIP device ordinal
+
+// `device` is the current device
+hipError_t static_scratch_address(int device, unsigned char **ptr) {
+	*ptr = nullptr;
+	if (device < 0 || device >= kStaticScratchDevices) return hipErrorInvalidDevice;
+	std::lock_guard<std::mutex> lock(g_static_scratch_mu);
+	if (!g_static_scratch_ptr[device]) {
+		void *p = nullptr;
+		const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_static_scratch));
+		if (e != hipSuccess) return e;
+		if (!p || ((uintptr_t)p & 255)) return hipErrorInvalidSymbol;
+		g_static_scratch_ptr[device] = (unsigned char *)p;
+	}
+	*ptr = g_static_scratch_ptr[device];
+	return hipSuccess;
+}
+
 } // namespace
 
 struct tokscore_ctx {
 	bool hostonly = false;
 	int device = -1;
+	unsigned char *static_scratch = nullptr; // this device's copy of g_static_scratch
 	int num_cus = 256;
 	hipStream_t stream = nullptr;
 	hipStream_t side = nullptr;      // boundary fix-up runs here, beside the histogram
@@ -883,6 +912,10 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	if (hipSetDevice(device) != hipSuccess) return TOKSCORE_E_NO_DEVICE;
 	tokscore_ctx *c = new tokscore_ctx();
 	c->device = device;
+	if (static_scratch_address(device, &c->static_scratch) != hipSuccess) {
+		delete c;
+		return TOKSCORE_E_HIP;
+	}
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
@@ -1294,6 +1327,66 @@ int tokscore_count_occurrences(tokscore_ctx *c, uint32_t max_cp, uint64_t *count
 	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("count_occurrences: ") + hipGetErrorString(e));
 	memcpy(counts, host.data(), (c->V + 3) * sizeof(uint64_t));
 	if (positions) *positions = host[c->V + 3];
+	return TOKSCORE_OK;
+}
+
+int tokscore_count_occurrences_static(tokscore_ctx *c, uint32_t max_cp, void *d_out, void *stream) {
+	if (!c || !d_out) return fail(c, TOKSCORE_E_ARG, "null output");
+	if (max_cp == 0) return fail(c, TOKSCORE_E_ARG, "max_cp must be at least 1");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	(void)hipSetDevice(c->device);
+	if (!c->vocab_set || !c->corpus_set) return fail(c, TOKSCORE_E_STATE, "vocabulary or corpus not set");
+	// bringing the trie to the device allocates: that is set-up, done by any earlier evaluation
+	if (!c->packed_valid || !c->device_trie_valid)
+		return fail(c, TOKSCORE_E_STATE,
+		            "the trie is not in device memory yet: run tokscore_count_occurrences or tokscore_score once "
+		            "before the first tokscore_count_occurrences_static");
+	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+	int st = apply_pending(c, s); // copies into existing slots only
+	if (st) return st;
+	const uint32_t n_ids = (uint32_t)c->V + 3;
+	TrieDev T = trie_dev(c);
+	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+	CountPlan plan;
+	if (!plan_count(T, c->packed.max_len, max_cp, n_ids, &plan))
+		return fail(c, TOKSCORE_E_CAPACITY, "tokens too long for the counting kernel's LDS tile");
+	// the static array, cut up: queue heads | first document of every tile | one row of partial
+	// counts per workgroup -- as many workgroups as fit, at most what the allocating call takes
+	const auto up256 = [](size_t n) { return (n + 255) & ~(size_t)255; };
+	const size_t tiles = count_tiles(c->total);
+	const size_t heads_bytes = up256(count_head_words(plan) * sizeof(uint32_t));
+	const size_t first_bytes = up256(std::max<size_t>(1, tiles) * sizeof(uint64_t));
+	const size_t row_bytes = ((size_t)n_ids + 1) * sizeof(uint32_t);
+	// (TOKSCORE_STATIC_LIMIT: use less of the array, for the tests of the two refusals below)
+	const size_t limit = (size_t)std::min<uint64_t>(kStaticScratchBytes, env_u64("TOKSCORE_STATIC_LIMIT", kStaticScratchBytes));
+	char msg[256];
+	if (heads_bytes + first_bytes + row_bytes > limit) {
+		snprintf(msg, sizeof msg,
+		         "count_occurrences_static: %zu bytes of scratch needed for %llu corpus bytes and %llu vocabulary entries, "
+		         "the static buffer holds %zu; use tokscore_count_occurrences",
+		         heads_bytes + first_bytes + row_bytes, (unsigned long long)c->total, (unsigned long long)c->V, limit);
+		return fail(c, TOKSCORE_E_CAPACITY, msg);
+	}
+	const uint32_t blocks = (uint32_t)std::min<size_t>(count_blocks(c->total, (uint32_t)c->num_cus),
+	                                                  (limit - heads_bytes - first_bytes) / row_bytes);
+	if (c->total / blocks >= 0x7FFFFFFFull / 4) {
+		snprintf(msg, sizeof msg, "count_occurrences_static: %llu corpus bytes over the %u workgroups the static buffer has "
+		                          "room for overflow a 32-bit partial count; use tokscore_count_occurrences",
+		         (unsigned long long)c->total, blocks);
+		return fail(c, TOKSCORE_E_CAPACITY, msg);
+	}
+	uint32_t *d_heads = (uint32_t *)c->static_scratch;
+	uint64_t *d_first = (uint64_t *)(c->static_scratch + heads_bytes);
+	uint32_t *d_slab = (uint32_t *)(c->static_scratch + heads_bytes + first_bytes);
+	// nothing here relies on what the previous call left behind: launch_count_all sets the heads,
+	// tile_first and every slab cell of the `blocks` rows are written before they are read
+	hipError_t e = hipMemsetAsync(d_out, 0, ((size_t)c->V + 4) * sizeof(unsigned long long), s);
+	if (e == hipSuccess) e = launch_count_all(T, C, plan, max_cp, n_ids, blocks, 2, d_heads, d_first, d_slab, s);
+	if (e == hipSuccess) {
+		launch_slab_reduce(d_slab, blocks, n_ids + 1, (unsigned long long *)d_out, s);
+		e = hipGetLastError();
+	}
+	if (e != hipSuccess) return fail(c, TOKSCORE_E_HIP, std::string("count_occurrences_static: ") + hipGetErrorString(e));
 	return TOKSCORE_OK;
 }
 
