@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace tokscore {
 
@@ -188,8 +189,8 @@ struct DirectLog {
 	__device__ __forceinline__ void close(const StreamDev &S, uint32_t lane) {
 		if (lane == 0) S.fill[batch] = cur / 2;
 	}
-	__device__ __forceinline__ void roll_if_full(const StreamDev &S, uint32_t lane) {
-		if (cur > kHighBytes) {
+	__device__ __forceinline__ void roll_if_full(const StreamDev &S, uint32_t lane, uint32_t high = kHighBytes) {
+		if (cur > high) {
 			close(S, lane);
 			open(S, lane);
 		}
@@ -338,27 +339,44 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 // The loop over rounds is hand-written gfx950 assembly (TOK_RANGES_ASM): the scan is bound by the
 // number of instructions a SIMD has to issue per lookup and by the two dependent LDS round trips
 // of a lookup (byte, then slot), so what counts is the instruction count, scalar ones included,
-// and that the next byte's read is under way while the finished tokens are logged.  Per lookup:
-// 17 vector, 3 LDS, 1 store and 12 scalar instructions, plus 15 per round for the refill (the compiler's
-// code for the same loop, kept below for TOKSCORE_ASM=0, needs about 50 per lookup).
+// and that the next byte's read is under way while the finished tokens are logged.  A round of K
+// lookups is unrolled (K is a template parameter): per lookup 17 vector, 3 LDS, 1 store and 10
+// scalar instructions with no loop counter and no branch, plus 18 per round for the refill, the log's
+// capacity check and the loop (the compiler's code for the same loop, kept below for TOKSCORE_ASM=0,
+// needs about 50 per lookup).
 // Conventions: exec = lanes still inside their range (ACT); v24 = the byte at cp, read at the end of
-// the previous lookup; v25-v29, s[38:43] scratch; IT = lookups left in the round - 1, all ones = a
-// round starts (refill first).  The block is left when no lane is active any more or when the log
-// block may not take another lookup (the C++ around it flushes and comes back), with nothing in
-// flight.
-#define TOK_RANGES_ASM(HIGH)                                                                 \
+// the previous lookup; v25-v29, s[38:43] scratch.  The block is entered and left at the start of a
+// round: left when no lane is active any more or when the stream batch may not take another round
+// (the C++ around it opens the next batch and comes back), with nothing in flight.
+#define TOK_RANGES_ASM(K, HIGH)                                                              \
 	asm volatile(                                                                             \
 	    "s_mov_b64 s[38:39], exec\n"                                                          \
 	    "s_mov_b64 %[act], %[actin]\n"                                                        \
 	    "s_mov_b64 %[req], %[reqin]\n"                                                        \
 	    "s_mov_b32 %[cur], %[curin]\n"                                                        \
-	    "s_mov_b32 %[it], %[itin]\n"                                                          \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
 	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
 	    "ds_read_u8 v24, v25\n"                                                               \
-	    "s_cmp_eq_u32 %[it], -1\n"                                                            \
-	    "s_cbranch_scc1 .Lround%=\n"                                                          \
-	    ".Ltop%=:\n"                                                                          \
+	    ".Lround%=:\n"                                /* refill, then a round of K lookups */ \
+	    "s_cmp_eq_u64 %[act], 0\n"                                                            \
+	    "s_cbranch_scc1 .Lout%=\n"                                                            \
+	    "s_cmp_gt_u32 %[cur], %[high]\n"              /* the batch may not take another round */ \
+	    "s_cbranch_scc1 .Lout%=\n"                                                            \
+	    "s_waitcnt vmcnt(4)\n"                        /* (in issue order: the piece came before the round's >= 4 stores) */ \
+	    "s_mov_b64 exec, %[req]\n"                    /* the piece asked for a round ago   */ \
+	    "v_and_or_b32 v25, %[fill], %[rmask], %[rbase]\n"                                     \
+	    "ds_write_b64 v25, %[data]\n"                                                         \
+	    "v_add_u32 %[fill], 8, %[fill]\n"                                                     \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    "v_sub_u32 v25, %[fill], %[lend]\n"                                                   \
+	    "v_cmp_ge_u32 vcc, %[room], v25\n"            /* room for another piece            */ \
+	    "s_mov_b64 %[req], vcc\n"                                                             \
+	    "s_mov_b64 exec, vcc\n"                                                               \
+	    "v_lshl_add_u32 v25, %[fill], 6, %[tb]\n"                                             \
+	    "s_waitcnt lgkmcnt(0)\n"                      /* (data is free again)              */ \
+	    "global_load_dwordx2 %[data], v25, %[tprep]\n"                                        \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    ".rept " #K "\n"                                                                      \
 	    "s_waitcnt lgkmcnt(0)\n"                                                              \
 	    "s_setprio 2\n"                               /* the dependent part of a lookup goes before other waves' logging */ \
 	    "v_add_u32 v25, %[nb], v24\n"                 /* slot t = LDS address of lt[t]     */ \
@@ -380,54 +398,30 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
 	    "ds_read_u8 v24, v25\n"                                                               \
 	    "s_setprio 0\n"                                                                       \
-	    "s_andn2_b64 s[42:43], exec, s[40:41]\n"      /* lanes whose token is complete     */ \
-	    "s_mov_b64 exec, s[42:43]\n"                                                          \
-	    "v_mbcnt_lo_u32_b32 v26, s42, 0\n"                                                    \
-	    "v_mbcnt_hi_u32_b32 v26, s43, v26\n"          /* rank among them                   */ \
+	    "s_andn2_b64 exec, exec, s[40:41]\n"          /* lanes whose token is complete     */ \
+	    "v_mbcnt_lo_u32_b32 v26, exec_lo, 0\n"                                                \
+	    "v_mbcnt_hi_u32_b32 v26, exec_hi, v26\n"      /* rank among them                   */ \
 	    "v_lshl_add_u32 v26, v26, 1, %[cur]\n"        /* byte offset in the wave's stream batch */ \
 	    "global_store_short v26, %[lslot], %[sbase]\n"                                        \
-	    "s_bcnt1_i32_b64 s40, s[42:43]\n"                                                     \
+	    "s_bcnt1_i32_b64 s40, exec\n"                                                         \
 	    "s_lshl1_add_u32 %[cur], s40, %[cur]\n"                                               \
 	    "v_cmp_ge_u32 vcc, %[cp], %[hi]\n"            /* range done                        */ \
 	    "s_andn2_b64 %[act], %[act], vcc\n"                                                   \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
-	    "s_add_u32 %[it], %[it], -1\n"                /* carry = lookups left in the round */ \
-	    "s_cbranch_scc0 .Lround%=\n"                                                          \
-	    ".Lcheck%=:\n"                                                                        \
-	    "s_cmp_gt_u32 %[cur], %[high]\n"                                                      \
-	    "s_cbranch_scc0 .Ltop%=\n"                                                            \
-	    "s_branch .Lout%=\n"                                                                  \
-	    ".Lround%=:\n"                                /* refill, then the next round       */ \
-	    "s_cmp_eq_u64 %[act], 0\n"                                                            \
-	    "s_cbranch_scc1 .Lout%=\n"                                                            \
-	    "s_waitcnt vmcnt(4)\n"                        /* (in issue order: the piece came before the round's >= 4 stores) */ \
-	    "s_mov_b64 exec, %[req]\n"                    /* the piece asked for a round ago   */ \
-	    "v_and_or_b32 v25, %[fill], %[rmask], %[rbase]\n"                                     \
-	    "ds_write_b64 v25, %[data]\n"                                                         \
-	    "v_add_u32 %[fill], 8, %[fill]\n"                                                     \
-	    "s_mov_b64 exec, %[act]\n"                                                            \
-	    "v_sub_u32 v25, %[fill], %[lend]\n"                                                   \
-	    "v_cmp_ge_u32 vcc, %[room], v25\n"            /* room for another piece            */ \
-	    "s_mov_b64 %[req], vcc\n"                                                             \
-	    "s_mov_b64 exec, vcc\n"                                                               \
-	    "v_lshl_add_u32 v25, %[fill], 6, %[tb]\n"                                             \
-	    "s_waitcnt lgkmcnt(0)\n"                      /* (data is free again)              */ \
-	    "global_load_dwordx2 %[data], v25, %[tprep]\n"                                        \
-	    "s_mov_b64 exec, %[act]\n"                                                            \
-	    "s_mov_b32 %[it], %[km1]\n"                                                           \
-	    "s_branch .Lcheck%=\n"                                                                \
+	    ".endr\n"                                                                             \
+	    "s_branch .Lround%=\n"                                                                \
 	    ".Lout%=:\n"                                                                          \
 	    "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                     \
 	    "s_mov_b64 exec, s[38:39]\n"                                                          \
 	    : [cp] "+v"(cp), [nb] "+v"(nb), [lend] "+v"(lend), [lslot] "+v"(lslot), [fill] "+v"(fill),      \
-	      [data] "+v"(data), [act] "=&s"(act_out), [req] "=&s"(req_out), [cur] "=&s"(cur_out),          \
-	      [it] "=&s"(it_out)                                                                            \
-	    : [actin] "s"(uni64(act)), [reqin] "s"(uni64(req)), [curin] "s"(uni32(log.cur)), [itin] "s"(uni32(it)), [sbase] "s"(uni64((unsigned long long)(uintptr_t)log.base)), \
+	      [data] "+v"(data), [act] "=&s"(act_out), [req] "=&s"(req_out), [cur] "=&s"(cur_out)           \
+	    : [actin] "s"(uni64(act)), [reqin] "s"(uni64(req)), [curin] "s"(uni32(log.cur)), [sbase] "s"(uni64((unsigned long long)(uintptr_t)log.base)), \
 	      [hi] "v"(end), [rbase] "v"(ring_a), [tb] "v"(tb), [rmask] "s"(RING - 1), [basea] "s"(label_bytes), \
-	      [high] "s"(HIGH), [k80] "s"(0x80u), [room] "s"(RING - 8), [km1] "s"(round - 1), [tprep] "s"(W.tprep)           \
+	      [high] "s"(HIGH), [k80] "s"(0x80u), [room] "s"(RING - 8), [tprep] "s"(W.tprep)                 \
 	    : "v24", "v25", "v26", "v27", "v28", "v29", "s38", "s39", "s40", "s41", "s42", "s43", "vcc", "scc", "memory")
 
-template <uint32_t RING, bool ASM>
+// K: lookups per round of the assembly loop (0: the C++ loop, rounds of W.round)
+template <uint32_t RING, uint32_t K>
 __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, StreamWork W, StreamDev Qd) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ranges_smem[];
 	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)ranges_smem;
@@ -447,7 +441,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 	__syncthreads();
 	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
 	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
-	if (ASM && (uint32_t)(uintptr_t)lds != 0) {
+	if (K != 0 && (uint32_t)(uintptr_t)lds != 0) {
 		// the assembly takes a slot index for the LDS address of its label (the image starts at LDS
 		// address 0: this kernel has no static LDS); reported like a stream overflow, never ignored
 		if (threadIdx.x == 0) Qd.cursor[1] = 1u;
@@ -485,19 +479,23 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 			}
 		}
 		wave_fence();
-		if constexpr (ASM) {
+		if constexpr (K != 0) {
 			const uint32_t ring_a = (uint32_t)(uintptr_t)ring;
 			const uint32_t tb = (uint32_t)((size_t)wb * rows * 64 + lane * 8); // (the transposed copy is below 4 GiB)
 			unsigned long long act = __builtin_amdgcn_ballot_w64(active), req = 0;
 			u32x2 data = {0, 0};
-			uint32_t it = 0xFFFFFFFFu;
+			constexpr uint32_t high = kBatchEntries * 2 - 128 * K; // a round adds at most 64 K entries
 			while (act != 0) {
 				unsigned long long act_out, req_out;
-				uint32_t cur_out, it_out;
-				TOK_RANGES_ASM(DirectLog::kHighBytes);
-				act = act_out, req = req_out, it = it_out;
+				uint32_t cur_out;
+				if constexpr (K == 4) TOK_RANGES_ASM(4, high);
+				else if constexpr (K == 5) TOK_RANGES_ASM(5, high);
+				else if constexpr (K == 6) TOK_RANGES_ASM(6, high);
+				else if constexpr (K == 7) TOK_RANGES_ASM(7, high);
+				else TOK_RANGES_ASM(8, high);
+				act = act_out, req = req_out;
 				log.cur = cur_out;
-				log.roll_if_full(Qd, lane);
+				log.roll_if_full(Qd, lane, high);
 			}
 		} else {
 			bool req = false;
@@ -906,13 +904,23 @@ void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const Strea
 		return !(e && atoi(e) == 0);
 	}();
 	if (use_asm) {
-		if (plan.ring == 32) go(&scan_ranges_kernel<32, true>);
-		else if (plan.ring == 64) go(&scan_ranges_kernel<64, true>);
-		else go(&scan_ranges_kernel<128, true>);
+		auto pick = [&](auto ring) {
+			constexpr uint32_t R = decltype(ring)::value;
+			switch (plan.round) {
+			case 4: go(&scan_ranges_kernel<R, 4>); break;
+			case 5: go(&scan_ranges_kernel<R, 5>); break;
+			case 6: go(&scan_ranges_kernel<R, 6>); break;
+			case 7: go(&scan_ranges_kernel<R, 7>); break;
+			default: go(&scan_ranges_kernel<R, 8>); break; // (plan_ranges_scan: 4 .. 8)
+			}
+		};
+		if (plan.ring == 32) pick(std::integral_constant<uint32_t, 32>{});
+		else if (plan.ring == 64) pick(std::integral_constant<uint32_t, 64>{});
+		else pick(std::integral_constant<uint32_t, 128>{});
 	} else {
-		if (plan.ring == 32) go(&scan_ranges_kernel<32, false>);
-		else if (plan.ring == 64) go(&scan_ranges_kernel<64, false>);
-		else go(&scan_ranges_kernel<128, false>);
+		if (plan.ring == 32) go(&scan_ranges_kernel<32, 0>);
+		else if (plan.ring == 64) go(&scan_ranges_kernel<64, 0>);
+		else go(&scan_ranges_kernel<128, 0>);
 	}
 }
 
