@@ -197,7 +197,21 @@ def moves_per_sec(scorer, tokens, corpus, off):
             scorer.score(incremental=incremental, out=buf)
         return len(which) / (time.perf_counter() - t0)
 
-    run(True, picks[:2])  # builds the occurrence index
+    # (iii) K = 64 independent moves judged by one tokscore_score_toggles call, none applied
+    batches = [rng.choice(multi, size=64, replace=False) for _ in range(6)]
+    scorer.score_toggles(batches[0], 0)  # builds the occurrence index
+    t0 = time.perf_counter()
+    deltas = [scorer.score_toggles(b, 0) for b in batches[1:]]
+    batched = 64 * len(deltas) / (time.perf_counter() - t0)
+    base_tt = scorer.score(out=buf)[1]
+    batched_exact = True
+    for k in (0, 21, 42, 63):  # against two full evaluations
+        scorer.toggle(int(batches[1][k]), False)
+        tt = scorer.score(out=buf)[1]
+        scorer.toggle(int(batches[1][k]), True)
+        batched_exact = batched_exact and int(deltas[0][k]) == tt - base_tt
+    scorer.score(out=buf)
+    run(True, picks[:2])
     inc = run(True, picks[2:])
     full = run(False, picks[2:42])
     docs = int(np.searchsorted(off, 1_000_000))
@@ -209,7 +223,8 @@ def moves_per_sec(scorer, tokens, corpus, off):
     st = gen.Generate(0, threads=threads, seed=5)[-1]
     host = st.gen_cnt / (time.perf_counter() - t0)
     gen.close()
-    return {"gpu_toggle_incremental_rescore": inc, "gpu_toggle_full_rescore": full,
+    return {"gpu_score_toggles_k64": batched, "gpu_score_toggles_k64_exact": batched_exact,
+            "gpu_toggle_incremental_rescore": inc, "gpu_toggle_full_rescore": full,
             "host_dag_loop": host, "host_threads": threads, "host_candidates": n_cand,
             "note": "moves/s; GPU: this shard and vocabulary, result on the host after every move"}
 

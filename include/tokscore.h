@@ -124,6 +124,21 @@ int tokscore_async_status(tokscore_ctx *ctx, void *stream, int *overflowed);
 int tokscore_score_incremental(tokscore_ctx *ctx, uint64_t *counts, uint64_t *total_tokens,
                                uint64_t *total_bytes);
 
+/* Batched move evaluation: what each of K annealing moves, taken alone, would do to the token
+ * count of the resident corpus -- the cost a move is judged on.  Move k = "set entry
+ * token_index[k] to enable[k]" against the vocabulary as it is now (toggles queued with
+ * tokscore_toggle are evaluated first); delta_total_tokens[k] = total_tokens with the move minus
+ * total_tokens without it, exactly what two full tokscore_score calls would give.  The moves are
+ * independent and nothing is changed: no entry is toggled, counts and state stay as they were.
+ * There is no reference counterpart on the corpus path: the reference estimates a move on the
+ * candidate DAG (TokenGenerator::SimulateStep, src/tokenizer/TokenGenerator.cpp:87).
+ * One batch = one look-up of the strings' chunks in the occurrence index, one search for the
+ * streams (about 256 bytes between two guaranteed token starts) that hold an occurrence, and one
+ * launch that walks each such stream with and without the move.  Vocabularies or corpora the
+ * stream scan does not take are served move by move with tokscore_score_incremental. */
+int tokscore_score_toggles(tokscore_ctx *ctx, const uint64_t *token_index, const int32_t *enable, uint64_t K,
+                           int64_t *delta_total_tokens);
+
 /* Closed-vocabulary all-occurrence counting: what
  * annealing::ExtractCandidates + Trie::AddString (src/tokenizer/GetTokens.cpp:21-27,
  * src/tokenizer/Trie.cpp:114-128) add up for the strings of the vocabulary -- for every
@@ -188,9 +203,12 @@ typedef struct {
 	uint64_t chunks;          /* wave work units of the scan kernel */
 	uint32_t slot_bits;       /* packed slot = label:8 | valid:1 | base:slot_bits, then id:id_bits */
 	uint32_t id_bits;
-	uint32_t scan_path;       /* 1 = LDS tile scan kernel, 0 = generic global-memory scan */
+	uint32_t scan_path;       /* 2 = LDS stream scan, 1 = LDS tile scan kernel, 0 = generic global-memory scan */
 	uint32_t rescored_chunks; /* chunks re-scanned by the last tokscore_score_incremental;
 	                           * UINT32_MAX when it ran (or fell back to) a full evaluation */
+	uint64_t toggle_streams;  /* streams walked (twice each) by the batched path of tokscore_score_toggles
+	                           * since the context was created; unchanged by a call the move-by-move
+	                           * fallback served */
 } tokscore_info;
 int tokscore_get_info(tokscore_ctx *ctx, tokscore_info *info);
 

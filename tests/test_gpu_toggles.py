@@ -1,0 +1,127 @@
+"""tokscore_score_toggles: K independent annealing moves judged in one call.  Each delta must equal
+total_tokens(vocabulary with the move) - total_tokens(vocabulary as it is) from the CPU oracle, and
+the call must leave the scorer's state as it found it."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as O
+import tokenizer_amd as ta
+from tokenizer_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_total(tokens, enabled, corpus, off):
+    # reference semantics of a disabled entry: a string that can never match
+    sub = [t if enabled[k] else b"\x00DISABLED" + str(k).encode() for k, t in enumerate(tokens)]
+    return O.OracleVocab(*synth.pack_vocab(sub)).score(corpus, off, threads=8)[1]
+
+
+def _check_moves(s, tokens, enabled, corpus, off, idx, en):
+    base = _oracle_total(tokens, enabled, corpus, off)
+    got = s.score_toggles(idx, en)
+    assert got.dtype == np.int64 and got.shape == (len(idx),)
+    for k, (i, e) in enumerate(zip(idx, en)):
+        moved = enabled.copy()
+        moved[i] = bool(e)
+        exp = _oracle_total(tokens, moved, corpus, off) - base
+        assert int(got[k]) == exp, (k, i, tokens[i], e, int(got[k]), exp)
+    return got
+
+
+@pytest.mark.parametrize("env", [{}, {"TOKSCORE_TOGGLE_ITEMS": "2000"}, {"TOKSCORE_SCAN": "tile"}])
+def test_deltas_equal_oracle_differences(env, monkeypatch):
+    """env: one batch / several batches (a small item budget) / the move-by-move fallback on a
+    scan path without the batched kernel."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    corpus, off = synth.wiki_like(1_500_000, seed=31)
+    tokens = synth.build_vocab(corpus[:500_000], 5000)
+    tokens.append(tokens[100])                       # a duplicate string: disabling one copy changes no boundary
+    tokens.append(b"The")                            # never matches the lower-cased corpus
+    tokens.append(bytes(corpus[700_000:700_014]).lower())  # rare and long
+    V = len(tokens)
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        base = s.score()
+        assert s.info().scan_path == (1 if env.get("TOKSCORE_SCAN") == "tile" else 2)
+        enabled = np.ones(V, dtype=bool)
+        rng = np.random.default_rng(7)
+        multi = [i for i, t in enumerate(tokens) if len(t) >= 2]
+        single = [i for i, t in enumerate(tokens) if len(t) == 1]
+        idx = [int(i) for i in rng.choice(multi, size=10, replace=False)]
+        idx += [100, V - 3, V - 2, V - 1, single[0], tokens.index(b" ") if b" " in tokens else single[-1]]
+        idx += [idx[0]]                               # the same move twice: independent, same answer
+        en = [0] * len(idx)
+        en[3] = 1                                     # enabling what is enabled: no move
+        got = _check_moves(s, tokens, enabled, corpus, off, idx, en)
+        assert got[3] == 0 and got[-1] == got[0]
+        assert (s.info().toggle_streams > 0) == (env.get("TOKSCORE_SCAN") != "tile"), "which path served the call"
+        assert any(int(d) != 0 for d in got)
+        # nothing was changed by asking
+        again = s.score(incremental=True)
+        assert np.array_equal(again[0], base[0]) and again[1:] == base[1:]
+        # moves against a vocabulary with entries disabled (two of them queued, not evaluated yet)
+        off_now = idx[:4]
+        for i in off_now[:2]:
+            s.toggle(i, False)
+            enabled[i] = False
+        s.score(incremental=True)
+        for i in off_now[2:]:
+            s.toggle(i, False)
+            enabled[i] = False
+        idx2 = off_now + [int(i) for i in rng.choice(multi, size=4, replace=False)]
+        en2 = [1, 1, 1, 0] + [0 if enabled[i] else 1 for i in idx2[4:]]
+        _check_moves(s, tokens, enabled, corpus, off, idx2, en2)
+        after = s.score()
+        assert after[1] == _oracle_total(tokens, enabled, corpus, off)
+    finally:
+        s.close()
+
+
+def test_deltas_on_cjk_and_many_moves():
+    corpus, off = synth.cjk_heavy(400_000, seed=9)
+    tokens = synth.build_vocab(corpus[:200_000], 9000)
+    V = len(tokens)
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        base = s.score()
+        assert s.info().scan_path == 2
+        enabled = np.ones(V, dtype=bool)
+        rng = np.random.default_rng(11)
+        multi = [i for i, t in enumerate(tokens) if len(t.decode("utf-8")) > 1]
+        idx = [int(i) for i in rng.choice(multi, size=64, replace=False)]
+        got = s.score_toggles(idx, 0)
+        assert s.info().toggle_streams > 0
+        # the oracle on a sample of the 64, the rest through the scorer's own full evaluations
+        for k in range(0, 64, 8):
+            moved = enabled.copy()
+            moved[idx[k]] = False
+            assert int(got[k]) == _oracle_total(tokens, moved, corpus, off) - base[1], (k, tokens[idx[k]])
+        for k in range(64):
+            s.toggle(idx[k], False)
+            tt = s.score()[1]
+            s.toggle(idx[k], True)
+            assert int(got[k]) == tt - base[1], (k, tokens[idx[k]])
+        assert np.all(got >= 0), "removing a token cannot shorten a greedy segmentation here"
+    finally:
+        s.close()
+
+
+def test_empty_and_invalid_arguments():
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab([b"a", b"ab"]))
+        s.set_corpus(*synth.pack_docs([b"abab", b"", b"b"]))
+        assert s.score_toggles([], []).shape == (0,)
+        assert list(s.score_toggles([1, 0, 1], [0, 0, 1])) == [2, 0, 0]  # "ab" off: ab ab -> a ? a ? (UNKNOWN b twice)
+        with pytest.raises(ta.TokscoreError):
+            s.score_toggles([2], [0])
+    finally:
+        s.close()

@@ -28,7 +28,8 @@ class TokscoreInfo(C.Structure):
     _fields_ = [("vocab_size", C.c_uint64), ("max_len", C.c_uint64), ("trie_nodes", C.c_uint64),
                 ("trie_slots", C.c_uint64), ("trie_lds_slots", C.c_uint64), ("corpus_bytes", C.c_uint64),
                 ("corpus_docs", C.c_uint64), ("chunks", C.c_uint64), ("slot_bits", C.c_uint32),
-                ("id_bits", C.c_uint32), ("scan_path", C.c_uint32), ("rescored_chunks", C.c_uint32)]
+                ("id_bits", C.c_uint32), ("scan_path", C.c_uint32), ("rescored_chunks", C.c_uint32),
+                ("toggle_streams", C.c_uint64)]
 
 
 # every symbol include/tokscore.h declares: (name, restype, argtypes)
@@ -49,6 +50,7 @@ _SIGNATURES = [
     ("tokscore_score_async", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("tokscore_async_status", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     ("tokscore_score_incremental", C.c_int, [C.c_void_p, _u64p, _u64p, _u64p]),
+    ("tokscore_score_toggles", C.c_int, [C.c_void_p, _u64p, C.POINTER(C.c_int32), C.c_uint64, C.POINTER(C.c_int64)]),
     ("tokscore_count_occurrences", C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
     ("tokscore_count_occurrences_static", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("tokscore_extract_candidates", C.c_int, [C.c_void_p, C.c_uint32, _u64p, _u64p]),
@@ -183,6 +185,17 @@ class Scorer:
         flag = C.c_int(0)
         self._check(self._lib.tokscore_async_status(self._h, stream_ptr, C.byref(flag)))
         return bool(flag.value)
+
+    def score_toggles(self, token_index, enable) -> np.ndarray:
+        """K independent moves judged at once: -> int64[K], total_tokens with entry token_index[k]
+        set to enable[k] minus total_tokens of the vocabulary as it is.  Nothing is changed."""
+        idx = np.ascontiguousarray(token_index, dtype=np.uint64)
+        en = np.ascontiguousarray(np.broadcast_to(np.asarray(enable, dtype=np.int32), idx.shape))
+        out = np.zeros(idx.shape[0], dtype=np.int64)
+        if idx.shape[0]:
+            self._check(self._lib.tokscore_score_toggles(self._h, _p64(idx), en.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                         idx.shape[0], out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out
 
     # ExtractCandidates + Trie::AddString on a closed vocabulary (GetTokens.cpp:21-27, Trie.cpp:114-128)
     def count_occurrences(self, max_cp: int):

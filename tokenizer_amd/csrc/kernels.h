@@ -101,6 +101,29 @@ struct StreamWork {
 	const uint32_t *sel_count; // ... and their number
 	const uint32_t *chunk_first; // [nchunks + 1] first stream of every chunk
 	uint32_t streams_per_chunk;  // upper bound of the streams in one chunk
+	// batched move evaluation (launch_walk_toggles): item = move << 32 | stream; nullptr = count
+	// every stream's tokens into tg_base
+	const unsigned long long *tg_items = nullptr;
+	uint32_t *tg_base = nullptr;        // [nstreams] tokens per stream under the vocabulary as it is
+	const uint32_t *tg_count = nullptr; // [kToggleLists] items appended per list (may exceed tg_cap: the surplus was not stored)
+	uint32_t tg_cap = 0;                // per list
+	const uint32_t *tg_slot = nullptr;  // [moves] the slot whose token-end bit the move flips
+	unsigned long long *tg_delta = nullptr; // [moves] tokens with the move - tokens without, mod 2^64
+};
+constexpr uint32_t kToggleLists = 64; // the items of a batch are kept in this many lists, one per lane of the walk
+// One batch of independent moves (tokscore_score_toggles).  All pointers are device memory.
+struct ToggleBatch {
+	uint32_t n;                 // moves
+	const uint32_t *index;      // occurrence index: rows of words_per_row words, one bit per chunk
+	uint32_t words_per_row;
+	const uint32_t *rows;       // [n] index row of the move's string
+	const uint32_t *pair_off;   // [n + 1] first (move, chunk) pair of every move; pair_off[m + 1] - pair_off[m] = chunks in its row
+	const uint32_t *str_off;    // [n + 1] the move's string in `codes`
+	const uint8_t *codes;       // strings in the prepared corpus' code space
+	uint32_t *pairs;            // [pair_off[n]] scratch: the chunk of every pair
+	unsigned long long *items;  // [kToggleLists][cap_items] scratch: (move, stream) for every stream the string occurs in
+	uint32_t *n_items;          // [kToggleLists] items per list, zeroed by the launcher
+	uint32_t cap_items;         // per list
 };
 struct StreamScanPlan {
 	uint32_t ring;            // bytes of a lane's LDS ring
@@ -115,6 +138,15 @@ void launch_prep_corpus(const CorpusDev &C, const ByteCodes &M, uint8_t *prep, u
 bool plan_stream_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan);
 void launch_scan_stream(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
                         hipStream_t stream);
+// Batched move evaluation.  launch_find_toggle_streams: the streams each move's string occurs in
+// (B.items / B.n_items), from the occurrence index and a search of the chunks it lists;
+// launch_walk_toggles: every listed stream walked with the move's token-end bit flipped, the
+// difference to its token count under the vocabulary as it is (W.tg_base, filled by the same
+// launcher when W.tg_items is null) added to W.tg_delta[move].  max_items bounds the work for the grid.
+void launch_find_toggle_streams(const ToggleBatch &B, const StreamWork &W, uint32_t npairs, uint32_t nchunks,
+                                hipStream_t stream);
+void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, uint64_t max_items,
+                         hipStream_t stream);
 // full evaluation over the transposed ranges (W.tprep)
 bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan);
 void launch_transpose_ranges(const uint8_t *prep, uint64_t prep_readable, uint32_t range_bytes, uint32_t halo, uint32_t nblocks,

@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) find_token_chunks_kernel(CorpusDev C, con
 				if (m < len) continue;
 				uint64_t j = p / chunk_bytes;
 				if (j >= nchunks) j = nchunks - 1;
-				if (p < begin[j]) j--; // the boundary was moved forward past p
+				while (p < begin[j]) j--; // the boundary was moved forward past p (chunks without a cut of their own are empty)
 				const uint32_t bit = 1u << (j & 31);
 				if (!(sel[j >> 5] & bit)) atomicOr(&sel[j >> 5], bit);
 			}
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) index_all_kernel(TrieDev T, CorpusDev C, 
 	for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < C.total; p += (uint64_t)gridDim.x * blockDim.x) {
 		uint64_t j = p / chunk_bytes;
 		if (j >= nchunks) j = nchunks - 1;
-		if (p < begin[j]) j--;
+		while (p < begin[j]) j--; // (begin[0] = 0; a chunk without a cut of its own is empty: begin[j] = begin[j + 1])
 		const uint32_t word = (uint32_t)(j >> 5), bit = 1u << (j & 31);
 		uint32_t nb = T.root_base;
 		for (uint64_t q = p; nb != 0 && q < C.total; q++) {

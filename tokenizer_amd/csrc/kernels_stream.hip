@@ -322,6 +322,294 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 	log.finish(Qd, lane);
 }
 
+// ---- batched move evaluation: which streams? -------------------------------------------------
+// pairs[pair_off[m] ..] = the chunks move m's string occurs in (its row of the occurrence index),
+// in any order; what the row's count promised and the bitmap does not hold is marked invalid.
+__global__ void __launch_bounds__(1024) list_toggle_pairs_kernel(ToggleBatch B) {
+	__shared__ uint32_t s_n;
+	const uint32_t m = blockIdx.x;
+	const uint32_t *row = B.index + (size_t)B.rows[m] * B.words_per_row;
+	const uint32_t base = B.pair_off[m], cap = B.pair_off[m + 1] - base;
+	if (threadIdx.x == 0) s_n = 0;
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < B.words_per_row; j += blockDim.x) {
+		uint32_t w = row[j];
+		if (!w) continue;
+		uint32_t at = atomicAdd(&s_n, (uint32_t)__builtin_popcount(w));
+		while (w) {
+			if (at < cap) B.pairs[base + at] = j * 32 + (uint32_t)__builtin_ctz(w);
+			w &= w - 1;
+			at++;
+		}
+	}
+	__syncthreads();
+	for (uint32_t j = s_n + threadIdx.x; j < cap; j += blockDim.x) B.pairs[base + j] = 0xFFFFFFFFu;
+}
+
+// One wave per (move, chunk) pair: the chunk's bytes of the prepared corpus are searched for the
+// move's string (in code space; a string with a byte the corpus cannot hold never matches), every
+// stream with an occurrence becomes one item.  Stream cuts are guaranteed token starts -- no trie
+// path crosses one -- so an occurrence lies inside one stream and a move changes nothing outside
+// the streams listed here.  The items go to kToggleLists lists (list = workgroup % kToggleLists,
+// one counter each, one atomic per workgroup: a single counter takes about 90 atomics per
+// microsecond, and a batch has hundreds of thousands of pairs); lane q of the walk reads list q.
+__global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B, StreamWork W, uint32_t nchunks) {
+	__shared__ uint32_t s_bits[16][16]; // per wave: up to 512 streams of one chunk (plan_stream: at most 8 * 64)
+	__shared__ uint32_t s_cnt[16], s_at[16];
+	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const uint32_t p = blockIdx.x * 16 + wave;
+	const uint32_t npairs = B.pair_off[B.n];
+	uint32_t m = 0, s0 = 0, ns = 0;
+	if (lane < 16) s_bits[wave][lane] = 0;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	const uint32_t chunk = p < npairs ? B.pairs[p] : 0xFFFFFFFFu;
+	if (chunk < nchunks) {
+		uint32_t lo = 0, hi = B.n; // the move: last m with pair_off[m] <= p
+		while (hi - lo > 1) {
+			const uint32_t mid = (lo + hi) >> 1;
+			if (B.pair_off[mid] <= p) lo = mid;
+			else hi = mid;
+		}
+		m = lo;
+		s0 = W.chunk_first[chunk];
+		const uint32_t s1 = W.chunk_first[chunk + 1];
+		ns = s1 - s0 < 512 ? s1 - s0 : 512;
+		const uint32_t a = W.pbeg[s0], b = W.pbeg[s1];
+		const uint32_t L = B.str_off[m + 1] - B.str_off[m];
+		const uint8_t *str = B.codes + B.str_off[m];
+		if (L >= 2 && b - a >= L) { // (a one-byte string cannot be toggled as a token end: the root row is all token ends)
+			// 16 positions per lane and step, the string's first four bytes compared as one dword at
+			// every byte alignment; what matches there is compared on from memory
+			uint32_t pat = 0;
+			for (uint32_t k = 0; k < 4 && k < L; k++) pat |= (uint32_t)str[k] << (8 * k);
+			const uint32_t msk = L >= 4 ? 0xFFFFFFFFu : (1u << (8 * L)) - 1u;
+			for (uint32_t base = (a & ~15u) + lane * 16; base < b; base += 64 * 16) {
+				const u32x4 v = *reinterpret_cast<const u32x4 *>(W.prep + base);
+				const uint32_t w[5] = {v[0], v[1], v[2], v[3], *reinterpret_cast<const uint32_t *>(W.prep + base + 16)};
+				uint32_t hits = 0; // bit 4 j + i: position base + 4 j + i
+#pragma unroll
+				for (uint32_t j = 0; j < 4; j++) {
+#pragma unroll
+					for (uint32_t i = 0; i < 4; i++) {
+						const uint32_t d = i == 0 ? w[j] : __builtin_amdgcn_alignbyte(w[j + 1], w[j], i);
+						hits |= ((d ^ pat) & msk) == 0 ? 1u << (4 * j + i) : 0u;
+					}
+				}
+				while (hits) {
+					const uint32_t q = base + (uint32_t)__builtin_ctz(hits);
+					hits &= hits - 1;
+					if (q < a || q + L > b) continue;
+					uint32_t k = 4;
+					while (k < L && W.prep[q + k] == str[k]) k++;
+					if (k < L) continue;
+					uint32_t l = s0, h = s0 + ns; // last stream with pbeg <= q
+					while (h - l > 1) {
+						const uint32_t mid = (l + h) >> 1;
+						if (W.pbeg[mid] <= q) l = mid;
+						else h = mid;
+					}
+					atomicOr(&s_bits[wave][(l - s0) >> 5], 1u << ((l - s0) & 31));
+				}
+			}
+		}
+	}
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	{
+		uint32_t n = lane < 16 ? (uint32_t)__builtin_popcount(s_bits[wave][lane]) : 0u;
+		for (int o = 8; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+		if (lane == 0) s_cnt[wave] = n;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t total = 0;
+		for (uint32_t k = 0; k < 16; k++) {
+			s_at[k] = total;
+			total += s_cnt[k];
+		}
+		const uint32_t first = total ? atomicAdd(&B.n_items[blockIdx.x % kToggleLists], total) : 0u;
+		for (uint32_t k = 0; k < 16; k++) s_at[k] += first;
+	}
+	__syncthreads();
+	unsigned long long *list = B.items + (size_t)(blockIdx.x % kToggleLists) * B.cap_items;
+	uint32_t at = s_at[wave];
+	for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+		const uint32_t i = i0 + lane;
+		const bool hit = i < ns && ((s_bits[wave][i >> 5] >> (i & 31)) & 1u);
+		const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
+		if (hit) {
+			const uint32_t r = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+			if (r < B.cap_items) list[r] = ((unsigned long long)m << 32) | (s0 + i);
+		}
+		at += (uint32_t)__builtin_popcountll(mask);
+	}
+}
+
+// ---- batched move evaluation: the walks ---------------------------------------------------------
+// The lookup loop of scan_stream_kernel, counting tokens per stream instead of logging them, with the
+// token-end bit of one slot flipped per lane (the move).  Without W.tg_items the items are all
+// streams and the counts go to W.tg_base (the vocabulary as it is: the context keeps them until a
+// toggle is applied); with it the items are the (move, stream) pairs of the kToggleLists lists, and
+// the difference to the stream's count in W.tg_base is added to W.tg_delta[move].
+// A wave owns a contiguous share of the items and a lane takes the next one of them whenever it has
+// finished a stream, so a wave's time is its share's bytes over 64 and not the sum of the longest
+// stream of every round.  Differences are summed per lane while the move stays the same (shares
+// follow the lists' order, which is the moves' order) and across the wave at the end: one address
+// takes about 90 atomics per microsecond.
+template <uint32_t RING>
+__global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, StreamWork W) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char walk_smem[];
+	__shared__ uint32_t s_count[kToggleLists];
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)walk_smem;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = uni32(threadIdx.x >> 6);
+	const uint32_t waves = blockDim.x >> 6;
+	const bool listed = W.tg_items != nullptr;
+	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
+	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
+	{
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
+		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		dst = (LDS_AS u32x4 *)(lds + label_bytes);
+		src = reinterpret_cast<const u32x4 *>(T.base);
+		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		if (threadIdx.x < kToggleLists) s_count[threadIdx.x] = listed ? min(W.tg_count[threadIdx.x], W.tg_cap) : 0u;
+	}
+	__syncthreads();
+	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
+	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
+	LDS_AS unsigned char *ring = lds + label_bytes + info_bytes + (wave * 64 + lane) * RING;
+
+	// flat item f: stream f, or entry f / kToggleLists of list f % kToggleLists
+	uint32_t total = W.nstreams;
+	if (listed) {
+		uint32_t most = s_count[lane];
+		for (int o = 32; o > 0; o >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, o, 64));
+		total = most * kToggleLists;
+	}
+	const uint32_t total_waves = gridDim.x * waves;
+	const uint32_t share = ((total + total_waves - 1) / total_waves + 63) & ~63u;
+	const uint64_t lo64 = (uint64_t)(blockIdx.x * waves + wave) * share;
+	uint32_t next = uni32(lo64 < total ? (uint32_t)lo64 : total);
+	const uint32_t stop = uni32(lo64 + share < total ? (uint32_t)(lo64 + share) : total);
+
+	bool active = false, req = false;
+	uint32_t beg = 0, end = 0, cp = 0, lend = 0, lslot = 0, nb = 0, fill = 0, ntok = 0;
+	uint32_t strm = 0, move = 0, flip_slot = 0xFFFFFFFFu;
+	uint32_t acc_move = 0xFFFFFFFFu;
+	int acc = 0;
+	u32x4 data = {0, 0, 0, 0};
+	auto finish = [&]() { // this lane's stream is done
+		if (!listed) {
+			W.tg_base[strm] = ntok;
+			return;
+		}
+		const int d = (int)ntok - (int)W.tg_base[strm]; // with the move - without
+		if (d == 0) return;
+		if (move != acc_move) {
+			if (acc != 0) atomicAdd(&W.tg_delta[acc_move], (unsigned long long)(long long)acc);
+			acc_move = move;
+			acc = 0;
+		}
+		acc += d;
+	};
+	for (;;) {
+		// ---- lanes without a stream take the next items of the wave's share ----
+		const unsigned long long idle = __builtin_amdgcn_ballot_w64(!active);
+		if (idle != 0 && next < stop) {
+			const uint32_t f = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+			next = uni32(next + (uint32_t)__builtin_popcountll(idle));
+			if (!active && f < stop) {
+				bool have = true;
+				strm = f;
+				if (listed) {
+					const uint32_t q = f % kToggleLists, idx = f / kToggleLists;
+					have = idx < s_count[q];
+					if (have) {
+						const unsigned long long it = W.tg_items[(size_t)q * W.tg_cap + idx];
+						strm = (uint32_t)it;
+						move = (uint32_t)(it >> 32);
+						flip_slot = W.tg_slot[move];
+					}
+				}
+				if (have) {
+					beg = W.pbeg[strm];
+					end = W.pbeg[strm + 1];
+					ntok = 0;
+					cp = lend = beg;
+					lslot = 0, nb = 0;
+					req = false;
+					if (beg < end) {
+						active = true;
+						fill = beg & ~15u;
+#pragma unroll
+						for (uint32_t k = 0; k < RING / 16; k++) {
+							const u32x4 x = *reinterpret_cast<const u32x4 *>(W.prep + fill);
+							*(LDS_AS u32x4 *)(ring + (fill & (RING - 1))) = x;
+							fill += 16;
+						}
+					} else {
+						finish(); // an empty stream (a dropped cut)
+					}
+				}
+			}
+		}
+		wave_fence();
+		if (__builtin_amdgcn_ballot_w64(active) == 0) {
+			if (next >= stop) break;
+			continue;
+		}
+		// ---- ring refill, as in scan_stream_kernel ----
+		if (req) {
+			*(LDS_AS u32x4 *)(ring + (fill & (RING - 1))) = data;
+			fill += 16;
+		}
+		req = active && (fill - lend) <= RING - 16;
+		if (req) data = *reinterpret_cast<const u32x4 *>(W.prep + fill);
+		wave_fence();
+		for (uint32_t it = 0; it < kRound; it++) {
+			if (active) {
+				const uint32_t c = ring[cp & (RING - 1)];
+				const uint32_t t = nb + c;
+				uint32_t x = l_lt[t] ^ c; // 0x80: hit on a token end, 0: hit, else miss
+				if (t == flip_slot) x ^= 0x80u;
+				const uint32_t b = l_base[t];
+				const uint32_t cp1 = cp + 1;
+				const bool term = x == 0x80u;
+				lend = term ? cp1 : lend;
+				lslot = term ? t : lslot;
+				nb = (x & 0x7Fu) == 0 ? b : 0u;
+				const bool cont = nb != 0;
+				cp = cont ? cp1 : lend;
+				if (!cont) {
+					ntok += lslot != 0 ? 1u : 0u; // (slot 0: a document separator, no token)
+					if (cp >= end) {
+						active = false;
+						req = false;
+						finish();
+					}
+				}
+			}
+			if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+		}
+	}
+	if (listed) {
+		// what the lanes still hold: one atomic per move and wave
+		unsigned long long pend = __builtin_amdgcn_ballot_w64(acc != 0);
+		while (pend) {
+			const uint32_t leader = (uint32_t)__builtin_ctzll(pend);
+			const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)acc_move, (int)leader);
+			const bool mine = acc != 0 && acc_move == m0;
+			int sum = mine ? acc : 0;
+			for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+			if (lane == leader) atomicAdd(&W.tg_delta[m0], (unsigned long long)(long long)sum);
+			pend &= ~__builtin_amdgcn_ballot_w64(mine);
+		}
+	}
+}
+
 // ---- full evaluation: equal ranges, refilled from the transposed corpus -------------------------
 // The ranges of one wave (64 consecutive ones) are stored interleaved in 8-byte pieces, piece k of
 // lane l's range at block + (k * 64 + l) * 8 (transpose_ranges_kernel), each range followed by
@@ -929,14 +1217,41 @@ void launch_scan_stream(const StreamTrieDev &T, const StreamWork &W, const Strea
 	if (plan.ring == 64) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_stream_kernel<64>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
-		hipLaunchKernelGGL(scan_stream_kernel<64>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream,
-		                   T, W, Q);
+		hipLaunchKernelGGL(scan_stream_kernel<64>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes,
+		                   stream, T, W, Q);
 	} else {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_stream_kernel<128>),
 		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
-		hipLaunchKernelGGL(scan_stream_kernel<128>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream,
-		                   T, W, Q);
+		hipLaunchKernelGGL(scan_stream_kernel<128>, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes,
+		                   stream, T, W, Q);
 	}
+}
+
+void launch_find_toggle_streams(const ToggleBatch &B, const StreamWork &W, uint32_t npairs, uint32_t nchunks,
+                                hipStream_t stream) {
+	(void)hipMemsetAsync(B.n_items, 0, kToggleLists * sizeof(uint32_t), stream);
+	if (B.n == 0 || npairs == 0) return;
+	hipLaunchKernelGGL(list_toggle_pairs_kernel, dim3(B.n), dim3(1024), 0, stream, B);
+	hipLaunchKernelGGL(find_toggle_streams_kernel, dim3((npairs + 15) / 16), dim3(1024), 0, stream, B, W, nchunks);
+}
+
+void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, uint64_t max_items,
+                         hipStream_t stream) {
+	if (max_items == 0) return;
+	// rings only beside the trie image (no log block): as many waves as fit
+	const uint32_t image = ((T.nslots + 15) & ~15u) + ((T.nslots * 2 + 15) & ~15u);
+	const uint32_t lds_total = 160 * 1024 - 1024; // static LDS and slack
+	const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(16, (lds_total - image) / (64 * plan.ring)));
+	const uint32_t lds_bytes = image + waves * 64 * plan.ring;
+	// every workgroup stages the whole trie image: no more of them than the items can keep busy
+	const uint64_t lanes_per_block = 64ull * waves;
+	const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(plan.blocks, (max_items + 2 * lanes_per_block - 1) / (2 * lanes_per_block)));
+	auto go = [&](auto kernel) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * waves), lds_bytes, stream, T, W);
+	};
+	if (plan.ring == 64) go(&walk_toggles_kernel<64>);
+	else go(&walk_toggles_kernel<128>);
 }
 
 void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,

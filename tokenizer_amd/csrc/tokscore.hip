@@ -138,6 +138,18 @@ struct tokscore_ctx {
 	bool uniform_chunks = false; // boundaries at multiples of chunk_bytes, each moved forward by < chunk_bytes
 	uint32_t *d_sel = nullptr;   // chunk bitmap of an incremental re-score
 	uint32_t *d_sel_list = nullptr; // the selected chunks as a list [nchunks] + 1 word: their number
+	// tokscore_score_toggles scratch, grown on demand: the batch description and results | the
+	// (move, chunk) pairs | the (move, stream) items
+	unsigned char *d_tg_meta = nullptr;
+	size_t tg_meta_cap = 0;
+	uint32_t *d_tg_pairs = nullptr;
+	size_t tg_pairs_cap = 0;
+	unsigned long long *d_tg_items = nullptr;
+	size_t tg_items_cap = 0;
+	uint32_t *d_stream_tokens = nullptr; // [nstreams] tokens per stream, valid while stream_tokens_epoch == trie_epoch
+	size_t stream_tokens_cap = 0;
+	uint64_t trie_epoch = 1, stream_tokens_epoch = 0; // trie_epoch: another one whenever the device trie or the plan changes
+	uint64_t toggle_items = 0; // (move, stream) items walked by score_toggles so far (diagnostics)
 	// occurrence index (one bit per string and chunk), built by the first incremental re-score of a plan
 	uint32_t *d_index = nullptr;
 	int index_state = 0; // 0 not tried, 1 built, -1 not available (too large / allocation failed)
@@ -167,6 +179,7 @@ struct tokscore_ctx {
 	bool chunks_synced = false;      // every chunk begins at a kept cut (what an incremental re-score needs)
 	uint32_t nstreams = 0;
 	uint32_t streams_per_chunk = 1;
+	uint32_t widest_chunk = 1; // most streams any chunk has
 	uint32_t range_bytes = 0;        // full evaluation: equal ranges of the prepared corpus, one per lane
 	uint32_t nranges = 0;
 	uint32_t *d_range_state = nullptr; // entry | exit_a | exit_b, nranges words each
@@ -294,6 +307,7 @@ void free_plan(tokscore_ctx *c) {
 	c->d_cursor = nullptr;
 	c->d_slab = nullptr;
 	c->plan_valid = false;
+	c->trie_epoch++;
 }
 
 // Work chunks, the unit the scan's work queue hands out -- the same unit of independence the
@@ -356,7 +370,7 @@ StreamWork stream_work(const tokscore_ctx *c, bool selected) {
 	W.sel_list = selected ? c->d_sel_list : nullptr;
 	W.sel_count = selected ? c->d_sel_list + c->nchunks : nullptr;
 	W.chunk_first = c->d_chunk_first;
-	W.streams_per_chunk = 2 * c->streams_per_chunk; // a chunk's first cut may have moved up to one chunk forward
+	W.streams_per_chunk = c->widest_chunk; // (a chunk's first cut may have moved forward, a chunk without one joined the one before)
 	return W;
 }
 
@@ -408,6 +422,7 @@ int ensure_trie(tokscore_ctx *c) {
 		                          c->stream));
 		HIP_TRY(c, hipStreamSynchronize(c->stream));
 		c->device_trie_valid = true;
+		c->trie_epoch++;
 		c->pending.clear();
 		c->pending_s.clear();
 		c->state_valid = false;
@@ -426,7 +441,8 @@ int ensure_trie(tokscore_ctx *c) {
 // Bring the device trie up to date with the host image: one 8-byte slot per pending toggle,
 // enqueued on s (in order after whatever still reads the old state there).
 int apply_pending(tokscore_ctx *c, hipStream_t s) {
-	if (c->pending.empty()) return TOKSCORE_OK;
+	if (c->pending.empty() && c->pending_s.empty()) return TOKSCORE_OK;
+	c->trie_epoch++;
 	if (c->device_trie_valid) {
 		const bool staged = c->h_patch && s == c->stream && !c->patch_in_flight && c->pending.size() <= kMaxPatch;
 		size_t k = 0;
@@ -533,20 +549,31 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 			if (!syn[j]) pb[j] = pb[j + 1]; // dropped cut: the stream before it runs on to the next kept one
 	}
 	// chunks: from every spc-th stream boundary, or the first kept cut after it (a chunk must begin
-	// where some lane begins a stream, or re-scanning it alone would not be exact)
+	// where some lane begins a stream, or re-scanning it alone would not be exact).  Without a kept
+	// cut in its range a chunk is empty and its bytes belong to the chunk before it.
 	c->h_chunk_begin.clear();
 	std::vector<uint32_t> cfirst;
-	c->chunks_synced = true;
 	for (size_t j = 0; j < ns; j += spc) {
 		size_t k = j;
 		while (k < ns && k < j + spc && !syn[k]) k++;
-		if (k == ns || k == j + spc) { // no kept cut in this chunk's range: no incremental re-scores on this plan
-			c->chunks_synced = false;
-			k = j;
-		}
-		cfirst.push_back((uint32_t)k);
-		c->h_chunk_begin.push_back(sb[k]);
+		cfirst.push_back(k == ns || k == j + spc ? 0xFFFFFFFFu : (uint32_t)k);
 	}
+	{
+		uint32_t next = (uint32_t)ns;
+		for (size_t j = cfirst.size(); j-- > 0;) {
+			if (cfirst[j] == 0xFFFFFFFFu) cfirst[j] = next;
+			next = cfirst[j];
+		}
+	}
+	uint32_t widest = 1;
+	for (size_t j = 0; j < cfirst.size(); j++) {
+		c->h_chunk_begin.push_back(cfirst[j] < ns ? sb[cfirst[j]] : c->total);
+		widest = std::max<uint32_t>(widest, (j + 1 < cfirst.size() ? cfirst[j + 1] : (uint32_t)ns) - cfirst[j]);
+	}
+	// (a lane per stream slot of every selected chunk: a corpus with a very long stretch without
+	// any guaranteed token start gets no incremental re-scores)
+	c->chunks_synced = widest <= 8 * spc;
+	c->widest_chunk = widest;
 	cfirst.push_back((uint32_t)ns);
 	c->h_chunk_begin.push_back(c->total);
 	c->nchunks = (uint32_t)(c->h_chunk_begin.size() - 1);
@@ -965,6 +992,10 @@ void tokscore_destroy(tokscore_ctx *c) {
 		if (c->d_slot_id) (void)hipFree(c->d_slot_id);
 		if (c->d_out) (void)hipFree(c->d_out);
 		if (c->h_out) (void)hipHostFree(c->h_out);
+		if (c->d_tg_meta) (void)hipFree(c->d_tg_meta);
+		if (c->d_tg_pairs) (void)hipFree(c->d_tg_pairs);
+		if (c->d_tg_items) (void)hipFree(c->d_tg_items);
+		if (c->d_stream_tokens) (void)hipFree(c->d_stream_tokens);
 		if (c->h_patch) (void)hipHostFree(c->h_patch);
 		for (auto &set : c->ring)
 			for (auto &e : set)
@@ -1278,6 +1309,184 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 	return TOKSCORE_OK;
 }
 
+// tokscore_score_toggles when the batched path does not apply: every move as toggle, incremental
+// re-score, toggle back (the same answers, one evaluation per move)
+static int score_toggles_one_by_one(tokscore_ctx *c, const uint64_t *token_index, const int32_t *enable, uint64_t K,
+                                    int64_t *delta) {
+	std::vector<uint64_t> counts(c->V + 3);
+	uint64_t base = 0, tt = 0;
+	int st = tokscore_score_incremental(c, counts.data(), &base, nullptr);
+	if (st) return st;
+	bool moved = false;
+	for (uint64_t k = 0; k < K; k++) {
+		delta[k] = 0;
+		const bool en = enable[k] != 0;
+		if (c->trie.Enabled(token_index[k]) == en) continue;
+		if ((st = tokscore_toggle(c, token_index[k], en))) return st;
+		st = tokscore_score_incremental(c, counts.data(), &tt, nullptr);
+		const int st2 = tokscore_toggle(c, token_index[k], !en);
+		if (st || st2) return st ? st : st2;
+		delta[k] = (int64_t)(tt - base);
+		moved = true;
+	}
+	if (moved) st = tokscore_score_incremental(c, counts.data(), &tt, nullptr); // the state as it was
+	return st;
+}
+
+int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const int32_t *enable, uint64_t K,
+                           int64_t *delta_total_tokens) {
+	if (!c || (K && (!token_index || !enable || !delta_total_tokens))) return fail(c, TOKSCORE_E_ARG, "null buffers");
+	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
+	if (!c->vocab_set) return fail(c, TOKSCORE_E_STATE, "vocabulary not set");
+	for (uint64_t k = 0; k < K; k++)
+		if (token_index[k] >= c->V) return fail(c, TOKSCORE_E_ARG, "token index out of range");
+	if (K == 0) return TOKSCORE_OK;
+	(void)hipSetDevice(c->device);
+	int st = ensure_trie(c);
+	if (st) return st;
+	if (!c->corpus_set) return fail(c, TOKSCORE_E_STATE, "corpus not set");
+	st = ensure_plan(c);
+	if (st) return st;
+	bool batched = c->scan_path == 2 && c->chunks_synced && c->uniform_chunks && c->simg_valid &&
+	               !env_u64("TOKSCORE_NOINCR", 0) && !env_u64("TOKSCORE_NOBATCH", 0);
+	if (batched && c->index_state == 0) build_index(c);
+	batched = batched && c->index_state == 1;
+	if (!batched) return score_toggles_one_by_one(c, token_index, enable, K, delta_total_tokens);
+	hipStream_t s = c->stream;
+	if (!c->pending.empty() || !c->pending_s.empty()) {
+		// toggles not evaluated yet: the moves are judged against the vocabulary as it is now
+		std::vector<uint64_t> counts(c->V + 3);
+		st = tokscore_score_incremental(c, counts.data(), nullptr, nullptr);
+		if (st) return st;
+	}
+	struct Move {
+		uint64_t k;
+		uint32_t row, slot, chunks;
+	};
+	std::vector<Move> moves;
+	for (uint64_t k = 0; k < K; k++) {
+		delta_total_tokens[k] = 0;
+		bool flips = false;
+		const int64_t t = c->trie.PeekStream(token_index[k], enable[k] != 0, c->simg, &flips);
+		const int32_t row = c->tok_row[token_index[k]];
+		if (t < 0 || !flips || row < 0 || c->row_chunks[row] == 0) continue; // nothing in this corpus can change
+		moves.push_back(Move{k, (uint32_t)row, (uint32_t)t, c->row_chunks[row]});
+	}
+	if (moves.empty()) return TOKSCORE_OK;
+	// tokens per stream under the vocabulary as it is: one walk over all streams, kept until the
+	// device trie changes
+	if (c->stream_tokens_epoch != c->trie_epoch) {
+		if ((size_t)c->nstreams + 1 > c->stream_tokens_cap) {
+			if (c->d_stream_tokens) (void)hipFree(c->d_stream_tokens);
+			c->d_stream_tokens = nullptr, c->stream_tokens_cap = 0;
+			HIP_TRY(c, hipMalloc((void **)&c->d_stream_tokens, ((size_t)c->nstreams + 1) * sizeof(uint32_t)));
+			c->stream_tokens_cap = (size_t)c->nstreams + 1;
+		}
+		StreamWork Wb = stream_work(c, false);
+		Wb.tg_base = c->d_stream_tokens;
+		launch_walk_toggles(stream_trie_dev(c), Wb, c->splan, c->nstreams, s);
+		HIP_TRY(c, hipGetLastError());
+		c->stream_tokens_epoch = c->trie_epoch;
+	}
+	const uint64_t per_chunk = c->widest_chunk; // no chunk has more streams (plan_stream)
+	const uint64_t budget = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 16ull << 20));
+	const StreamWork W0 = stream_work(c, false);
+	size_t first = 0;
+	std::vector<uint32_t> meta;
+	std::vector<uint8_t> codes;
+	while (first < moves.size()) {
+		// a batch: as many moves as the item budget holds (one at least)
+		size_t last = first;
+		uint64_t pairs = 0;
+		while (last < moves.size() && (last == first || (pairs + moves[last].chunks) * per_chunk <= budget)) pairs += moves[last++].chunks;
+		const uint32_t n = (uint32_t)(last - first);
+		if (pairs > 0xFFFFFFF0ull / per_chunk / 2) return fail(c, TOKSCORE_E_CAPACITY, "score_toggles: a move touches too many streams for one launch");
+		// items: kToggleLists lists; list q takes what the workgroups q, q + kToggleLists, .. of the search find
+		// (16 pairs per workgroup), so this many entries per list always suffice
+		const uint64_t find_blocks = (pairs + 15) / 16;
+		const uint64_t list_cap = (find_blocks + kToggleLists - 1) / kToggleLists * 16 * per_chunk;
+		const uint64_t cap_items = list_cap * kToggleLists;
+		// device blob: delta[n] (u64) | items per list [kToggleLists] | rows[n] | pair_off[n+1] | slots[n] | str_off[n+1] | codes
+		meta.clear();
+		codes.clear();
+		meta.resize((size_t)2 * n + kToggleLists, 0); // delta and the item counters start at zero
+		const size_t rows_at = meta.size();
+		for (uint32_t m = 0; m < n; m++) meta.push_back(moves[first + m].row);
+		const size_t poff_at = meta.size();
+		uint32_t acc = 0;
+		for (uint32_t m = 0; m < n; m++) {
+			meta.push_back(acc);
+			acc += moves[first + m].chunks;
+		}
+		meta.push_back(acc);
+		const size_t slots_at = meta.size();
+		for (uint32_t m = 0; m < n; m++) meta.push_back(moves[first + m].slot);
+		const size_t soff_at = meta.size();
+		for (uint32_t m = 0; m < n; m++) {
+			meta.push_back((uint32_t)codes.size());
+			const uint64_t tok = token_index[moves[first + m].k];
+			for (uint64_t i = c->h_vocab_off[tok]; i < c->h_vocab_off[tok + 1]; i++) codes.push_back(c->simg.code[c->h_vocab_bytes[i]]);
+		}
+		meta.push_back((uint32_t)codes.size());
+		const size_t codes_at = meta.size() * sizeof(uint32_t);
+		const size_t blob = codes_at + ((codes.size() + 15) & ~(size_t)15) + 16;
+		if (blob > c->tg_meta_cap) {
+			if (c->d_tg_meta) (void)hipFree(c->d_tg_meta);
+			c->d_tg_meta = nullptr, c->tg_meta_cap = 0;
+			HIP_TRY(c, hipMalloc((void **)&c->d_tg_meta, blob * 2));
+			c->tg_meta_cap = blob * 2;
+		}
+		if (pairs > c->tg_pairs_cap) {
+			if (c->d_tg_pairs) (void)hipFree(c->d_tg_pairs);
+			c->d_tg_pairs = nullptr, c->tg_pairs_cap = 0;
+			HIP_TRY(c, hipMalloc((void **)&c->d_tg_pairs, pairs * sizeof(uint32_t)));
+			c->tg_pairs_cap = pairs;
+		}
+		if (cap_items > c->tg_items_cap) {
+			if (c->d_tg_items) (void)hipFree(c->d_tg_items);
+			c->d_tg_items = nullptr, c->tg_items_cap = 0;
+			HIP_TRY(c, hipMalloc((void **)&c->d_tg_items, cap_items * sizeof(unsigned long long)));
+			c->tg_items_cap = cap_items;
+		}
+		HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta, meta.data(), codes_at, hipMemcpyHostToDevice, s));
+		if (!codes.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta + codes_at, codes.data(), codes.size(), hipMemcpyHostToDevice, s));
+		uint32_t *words = (uint32_t *)c->d_tg_meta;
+		ToggleBatch B;
+		B.n = n;
+		B.index = c->d_index;
+		B.words_per_row = (c->nchunks + 31) / 32;
+		B.rows = words + rows_at;
+		B.pair_off = words + poff_at;
+		B.str_off = words + soff_at;
+		B.codes = c->d_tg_meta + codes_at;
+		B.pairs = c->d_tg_pairs;
+		B.items = c->d_tg_items;
+		B.n_items = words + 2 * n;
+		B.cap_items = (uint32_t)list_cap;
+		StreamWork W = W0;
+		W.tg_items = c->d_tg_items;
+		W.tg_count = B.n_items;
+		W.tg_cap = B.cap_items;
+		W.tg_slot = words + slots_at;
+		W.tg_base = c->d_stream_tokens;
+		W.tg_delta = (unsigned long long *)c->d_tg_meta;
+		launch_find_toggle_streams(B, W, (uint32_t)pairs, c->nchunks, s);
+		launch_walk_toggles(stream_trie_dev(c), W, c->splan, cap_items, s);
+		HIP_TRY(c, hipGetLastError());
+		std::vector<uint64_t> res((size_t)n + kToggleLists / 2);
+		HIP_TRY(c, hipMemcpyAsync(res.data(), c->d_tg_meta, res.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+		HIP_TRY(c, hipStreamSynchronize(s));
+		const uint32_t *per_list = reinterpret_cast<const uint32_t *>(res.data() + n);
+		for (uint32_t q = 0; q < kToggleLists; q++) {
+			if (per_list[q] > B.cap_items) return fail(c, TOKSCORE_E_INTERNAL, "score_toggles: more streams than the chunks can hold");
+			c->toggle_items += per_list[q];
+		}
+		for (uint32_t m = 0; m < n; m++) delta_total_tokens[moves[first + m].k] = (int64_t)res[m];
+		first = last;
+	}
+	return TOKSCORE_OK;
+}
+
 int tokscore_count_occurrences(tokscore_ctx *c, uint32_t max_cp, uint64_t *counts, uint64_t *positions) {
 	if (!c || !counts) return fail(c, TOKSCORE_E_ARG, "null output");
 	if (max_cp == 0) return fail(c, TOKSCORE_E_ARG, "max_cp must be at least 1");
@@ -1516,6 +1725,7 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 		info->trie_lds_slots = c->scan_path == 2 ? (uint32_t)c->simg.lt.size() : c->tile.lds_slots;
 	}
 	info->rescored_chunks = c->rescored_chunks;
+	info->toggle_streams = c->toggle_items;
 	return TOKSCORE_OK;
 }
 

@@ -445,6 +445,23 @@ int64_t VocabTrie::PatchStream(uint64_t token, StreamImage *img) const {
 	return t;
 }
 
+int64_t VocabTrie::PeekStream(uint64_t token, bool enable, const StreamImage &img, bool *flips) {
+	*flips = false;
+	if (token >= V_ || !img.valid || node_sslot_.empty()) return -1;
+	const uint32_t node = tok_node_[token];
+	if (node == 0) return -1;
+	const uint32_t t = node_sslot_[node];
+	if (!t) return -1;
+	const uint8_t was = enabled_[token];
+	enabled_[token] = enable ? 1 : 0;
+	uint8_t lt;
+	uint32_t id;
+	StreamSlotValues(node, img.lt[t] & 0x7Fu, &lt, &id);
+	enabled_[token] = was;
+	*flips = ((lt ^ img.lt[t]) & 0x80u) != 0;
+	return t;
+}
+
 uint32_t VocabTrie::StringRows(uint64_t nslots, std::vector<int32_t> *slot_row, std::vector<int32_t> *tok_row) const {
 	slot_row->assign(nslots, -1);
 	tok_row->assign(V_, -1);

@@ -92,6 +92,11 @@ public:
 	// After Toggle(token): bring the image's slot of that token's node up to date; returns the
 	// slot (or -1 when the node is not in the image / nothing changed).
 	int64_t PatchStream(uint64_t token, StreamImage *img) const;
+	// What PatchStream would do after Toggle(token, enable), with nothing changed: the token's slot
+	// in the image (-1: none) and whether its token-end bit would flip (the only thing a toggle can
+	// change about where tokens end; the id a slot counts for does not move a boundary).
+	int64_t PeekStream(uint64_t token, bool enable, const StreamImage &img, bool *flips);
+	bool Enabled(uint64_t token) const { return token < V_ && enabled_[token] != 0; }
 
 	// Rows of a per-string table (one row per distinct non-empty token string): slot_row[t] = row
 	// of the node at slot t or -1, tok_row[i] = row of token i's string or -1.  After Pack.
