@@ -109,6 +109,22 @@ int tokanneal_apply_step(tokanneal_gen *g, uint64_t i, int enable, double *delta
 /* uses on the l / r side and the enabled flag of token i as they stand. */
 int tokanneal_token_state(const tokanneal_gen *g, uint64_t i, uint64_t *l_uses, uint64_t *r_uses, int *enabled);
 
+/* Moves judged on the corpus instead of on the DAG: when `evaluate` is set it replaces the estimate
+ * TokenGenerator::RunBatch takes from Token::SimulateStep (TokenGenerator.cpp:87) for all the moves
+ * of a batch at once -- delta_raw[k] = what candidate cand[k] is worth in the raw score's unit
+ * (tokens the corpus is shorter by with it enabled), each judged alone against the state as it
+ * stands; tokscore_score_toggles (include/tokscore.h) computes exactly that on the GPU.  `applied`
+ * is told every accepted move, `resync` is asked for the exact raw score after every batch (both
+ * optional).  The DAG keeps following the accepted moves (GetSolution orders by it).  Callbacks
+ * return 0 on success; a failure surfaces as TOKANNEAL_E_DATA from tokanneal_worker_task /
+ * tokanneal_generate.  With an evaluator tokanneal_generate runs one worker.  evaluate = NULL
+ * restores the reference's DAG estimate. */
+typedef int (*tokanneal_evaluate_fn)(void *user, const uint32_t *cand, uint64_t n, int enable, double *delta_raw);
+typedef int (*tokanneal_applied_fn)(void *user, uint32_t cand, int enable);
+typedef int (*tokanneal_resync_fn)(void *user, double *raw_score);
+int tokanneal_set_evaluator(tokanneal_gen *g, tokanneal_evaluate_fn evaluate, tokanneal_applied_fn applied,
+                            tokanneal_resync_fn resync, void *user);
+
 /* The deterministic seeding option: (re)seeds the generator tokanneal_worker_task draws from
  * (std::mt19937, as TokenGenerator.cpp:51-53 but with a given seed instead of random_device). */
 int tokanneal_seed(tokanneal_gen *g, uint32_t seed);

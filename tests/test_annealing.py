@@ -291,3 +291,103 @@ def test_undoing_every_move_restores_the_counts(trace, golden_bin):
     assert raw == 0
     for i in range(n):
         assert gen.token_state(i) == (int(uses[i]), int(uses[i]), rpar[i] == A.NONE)
+
+
+# ---- moves judged by an evaluator instead of the DAG (tokanneal_set_evaluator) ----------------
+
+def test_evaluator_that_returns_the_dag_estimate_changes_nothing(trace, golden_bin):
+    """With one move per batch, an evaluator that answers with Token::SimulateStep's own value
+    must walk the very same trajectory as the DAG path (same seed, same draws, same decisions)."""
+    _, toks = A.ReadTokens(golden_bin)
+    plain = A.TokenGenerator(toks, trace["pref"], 1)
+    _, toks = A.ReadTokens(golden_bin)
+    judged = A.TokenGenerator(toks, trace["pref"], 1)
+
+    class Dag:
+        calls = 0
+
+        def evaluate(self, cands, enable):
+            Dag.calls += 1
+            return [judged.SimulateStep(int(c)) for c in cands]
+
+    judged.set_evaluator(Dag())
+    plain.seed(7)
+    judged.seed(7)
+    for k in range(400):
+        plain.WorkerTask()
+        judged.WorkerTask()
+        a, b = plain.state().as_dict(), judged.state().as_dict()
+        assert a == b, k
+    assert Dag.calls == 400
+    assert plain.GetSolution() == judged.GetSolution()
+    judged.set_evaluator(None)          # back on the DAG
+    plain.WorkerTask()
+    judged.WorkerTask()
+    assert plain.state().as_dict() == judged.state().as_dict()
+
+
+def test_corpus_judged_moves_keep_the_raw_score_exact():
+    """The GPU evaluator's protocol with the CPU oracle in the scorer's place: values are exact
+    token-count differences of the corpus, accepted moves are reported, and after every batch the
+    raw score is the tokens saved against the single-code-point start."""
+    texts = ["the cat sat on the mat. the cat ate the rat.", "a cat, a mat, a rat and a bat",
+             "日本語の本 日本の本", "that hat that sat"] * 3
+    corpus, off = pack_docs(texts)
+    toks = A.GetTokens(corpus, off, 4)
+    names = toks.names()
+    rpar = toks.arrays()[3]
+    n = len(names)
+    enabled = rpar == A.NONE
+
+    def total(mask):
+        sub = [t if mask[k] else b"\x00OFF" + str(k).encode() for k, t in enumerate(names)]
+        b = np.frombuffer(b"".join(sub), dtype=np.uint8)
+        o = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(t) for t in sub], out=o[1:])
+        return O.OracleVocab(b, o).score(corpus, off)[1]
+
+    class Judge:
+        start = total(enabled)
+        log = []
+
+        def evaluate(self, cands, enable):
+            base = total(enabled)
+            vals = []
+            for c in cands:
+                assert bool(enabled[c]) != enable
+                m = enabled.copy()
+                m[c] = enable
+                d = total(m) - base
+                vals.append(-d if enable else d)
+            Judge.log.append((len(cands), enable))
+            return vals
+
+        def applied(self, cand, enable):
+            enabled[cand] = enable
+
+        def resync(self):
+            return float(Judge.start - total(enabled))
+
+    gen = A.TokenGenerator(toks, 40, 8, evaluator=Judge())
+    gen.seed(3)
+    for k in range(30):
+        gen.WorkerTask()
+        st = gen.state()
+        assert st.raw_score == Judge.start - total(enabled), k
+        on = [i for i in range(n) if rpar[i] != A.NONE and gen.token_state(i)[2]]
+        assert on == [i for i in range(n) if rpar[i] != A.NONE and enabled[i]], k
+        assert st.enabled_cnt == len(on)
+    assert sum(c for c, _ in Judge.log) == 30 * 8
+    assert st.raw_score > 0, "judged on the corpus the annealer must find tokens that shorten it"
+
+
+def test_a_failing_evaluator_surfaces_as_its_own_exception(golden_bin):
+    _, toks = A.ReadTokens(golden_bin)
+
+    class Broken:
+        def evaluate(self, cands, enable):
+            raise KeyError("no corpus")
+
+    gen = A.TokenGenerator(toks, 50, 4, evaluator=Broken())
+    with pytest.raises(KeyError):
+        gen.WorkerTask()

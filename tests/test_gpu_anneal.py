@@ -162,3 +162,46 @@ def test_extract_candidates_rejects_what_it_cannot_take():
         assert len(s.extract_candidates(5)[0]) == 0
     finally:
         s.close()
+
+
+def test_moves_judged_on_the_gpu_keep_the_books():
+    """evaluator="gpu": GpuMoveEvaluator behind tokanneal_set_evaluator.  After every batch the raw
+    score must be the tokens saved against the start, the scorer's enabled set the generator's, and
+    the scorer's token count what the CPU oracle gets for that set."""
+    corpus, off = synth.wiki_like(120_000, seed=41)
+    corpus = np.frombuffer(bytes(corpus).lower(), dtype=np.uint8)
+    toks = A.GetTokens(corpus, off, 3)
+    names = toks.names()
+    rpar = toks.arrays()[3]
+    n = len(names)
+    judge = A.GpuMoveEvaluator(toks, corpus, off)
+    gen = A.TokenGenerator(toks, 400, 32, evaluator=judge)
+    try:
+        gen.seed(5)
+        for k in range(12):
+            gen.WorkerTask()
+            st = gen.state()
+            assert st.raw_score == judge.start_tokens - judge.total_tokens, k
+        assert judge.calls >= 12 and judge.moves == 12 * 32
+        on = np.array([rpar[i] == A.NONE or gen.token_state(i)[2] for i in range(n)])
+        sub = [t if on[k] else b"\x00OFF" + str(k).encode() for k, t in enumerate(names)]
+        exp = O.OracleVocab(*synth.pack_vocab(sub)).score(corpus, off, threads=8)
+        assert judge.scorer.score()[1] == exp[1] == judge.total_tokens
+        assert st.raw_score > 0 and st.enabled_cnt == int(on.sum()) - int((rpar == A.NONE).sum())
+    finally:
+        gen.close()
+        judge.close()
+
+
+def test_anneal_and_score_with_the_gpu_evaluator():
+    corpus, off = synth.wiki_like(60_000, seed=42)
+    corpus = np.frombuffer(bytes(corpus).lower(), dtype=np.uint8)
+    sol, counts, tt, tb = A.anneal_and_score(corpus, off, max_len=3, pref_token_count=300, pass_cnt=0, batch_size=64,
+                                             threads=1, seed=9, evaluator="gpu")
+    try:
+        assert tb == len(corpus) and 0 < tt < tb
+        voc = O.OracleVocab(*synth.pack_vocab(sol.tokens))
+        exp = voc.score(corpus, off, threads=8)
+        assert (tt, tb) == exp[1:] and np.array_equal(counts, exp[0])
+    finally:
+        sol.close()

@@ -63,6 +63,7 @@ _SIGNATURES = [
     ("tokanneal_apply_step", C.c_int, [_vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]),
     ("tokanneal_token_state", C.c_int, [_vp, C.c_uint64, _u64p, _u64p, C.POINTER(C.c_int)]),
     ("tokanneal_seed", C.c_int, [_vp, C.c_uint32]),
+    ("tokanneal_set_evaluator", C.c_int, [_vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("tokanneal_worker_task", C.c_int, [_vp]),
     ("tokanneal_generate", C.c_int, [_vp, C.c_uint64, C.c_uint32, C.c_int64, C.POINTER(State), C.c_uint64, _u64p]),
     ("tokanneal_get_state", C.c_int, [_vp, C.POINTER(State)]),
@@ -237,16 +238,108 @@ def WriteTokens(path, tokens: Tokens):
     _check(load_library().tokanneal_cands_write(tokens._h, os.fsencode(path)))
 
 
-class TokenGenerator:
-    """annealing::TokenGenerator (TokenGenerator.h:15-53).  `tokens` is consumed."""
+_EVALUATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _u32p, C.c_uint64, C.c_int, C.POINTER(C.c_double))
+_APPLIED_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_int)
+_RESYNC_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
 
-    def __init__(self, tokens: Tokens, pref_token_count: int, batch_size: int = None):
+
+class GpuMoveEvaluator:
+    """Judges the annealer's moves on a corpus resident on the GPU instead of on the candidate DAG:
+    a Scorer whose vocabulary is the whole candidate set (entry i = candidate i), with exactly the
+    generator's enabled candidates enabled.  The value of a move is its exact effect on the corpus'
+    token count (Scorer.score_toggles, one call per batch); the raw score is the tokens saved
+    against the single-code-point vocabulary the generator starts from."""
+
+    def __init__(self, tokens: Tokens, corpus, doc_off, device: int = 0):
+        from . import Scorer
+        names = tokens.names()
+        _, _, _, rpar = tokens.arrays()
+        self.scorer = Scorer(device)
+        b = np.frombuffer(b"".join(names), dtype=np.uint8) if names else np.zeros(0, dtype=np.uint8)
+        off = np.zeros(len(names) + 1, dtype=np.uint64)
+        np.cumsum([len(n) for n in names], out=off[1:])
+        self.scorer.set_vocab(b, off)
+        self.scorer.set_corpus(corpus, doc_off)
+        for i in np.nonzero(rpar != NONE)[0]:  # everything but the single code points starts disabled (TokenGenerator.cpp:27-48)
+            self.scorer.toggle(int(i), False)
+        self.start_tokens = self.scorer.score()[1]
+        self.total_tokens = self.start_tokens
+        self.calls = 0
+        self.moves = 0
+
+    def evaluate(self, cands, enable: bool):
+        d = self.scorer.score_toggles(cands, 1 if enable else 0).astype(np.float64)
+        self.calls += 1
+        self.moves += len(cands)
+        return -d if enable else d
+
+    def applied(self, cand: int, enable: bool):
+        self.scorer.toggle(int(cand), bool(enable))
+
+    def resync(self) -> float:
+        self.total_tokens = self.scorer.score(incremental=True)[1]
+        return float(self.start_tokens - self.total_tokens)
+
+    def close(self):
+        self.scorer.close()
+
+
+class TokenGenerator:
+    """annealing::TokenGenerator (TokenGenerator.h:15-53).  `tokens` is consumed.
+    evaluator: None = the reference's estimate on the candidate DAG (Token::SimulateStep);
+    an object with evaluate(cands, enable) -> values, applied(cand, enable), resync() -> raw score
+    (GpuMoveEvaluator) = moves judged by it, a batch per call (include/tokanneal.h)."""
+
+    def __init__(self, tokens: Tokens, pref_token_count: int, batch_size: int = None, evaluator=None):
         self._lib = load_library()
         if batch_size is None:  # the reference's default argument (TokenGenerator.h:49)
             batch_size = os.cpu_count() or 1
         self._h = C.c_void_p()
         _check(self._lib.tokanneal_gen_create(C.byref(self._h), C.byref(tokens._h), pref_token_count, batch_size))
         tokens._h = None
+        self._evaluator = None
+        self._callback_error = None
+        if evaluator is not None:
+            self.set_evaluator(evaluator)
+
+    def set_evaluator(self, evaluator):
+        self._evaluator = evaluator
+        if evaluator is None:
+            self._callbacks = None
+            _check(self._lib.tokanneal_set_evaluator(self._h, None, None, None, None))
+            return
+
+        def guard(f):
+            def run(*a):
+                try:
+                    f(*a)
+                    return 0
+                except BaseException as e:  # noqa: B902 -- must not unwind through the C frames
+                    self._callback_error = e
+                    return 1
+            return run
+
+        def evaluate(_user, cand, n, enable, out):
+            vals = evaluator.evaluate(np.ctypeslib.as_array(cand, shape=(int(n),)).copy(), bool(enable))
+            for k in range(int(n)):
+                out[k] = float(vals[k])
+
+        def applied(_user, cand, enable):
+            evaluator.applied(int(cand), bool(enable))
+
+        def resync(_user, raw):
+            raw[0] = float(evaluator.resync())
+
+        self._callbacks = (_EVALUATE_FN(guard(evaluate)),
+                           _APPLIED_FN(guard(applied)) if hasattr(evaluator, "applied") else None,
+                           _RESYNC_FN(guard(resync)) if hasattr(evaluator, "resync") else None)
+        _check(self._lib.tokanneal_set_evaluator(self._h, *[C.cast(f, C.c_void_p) if f else None for f in self._callbacks], None))
+
+    def _checked(self, status):
+        err, self._callback_error = self._callback_error, None
+        if err is not None:
+            raise err
+        _check(status)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -277,7 +370,7 @@ class TokenGenerator:
         _check(self._lib.tokanneal_seed(self._h, seed & 0xFFFFFFFF))
 
     def WorkerTask(self):  # TokenGenerator.cpp:107-158
-        _check(self._lib.tokanneal_worker_task(self._h))
+        self._checked(self._lib.tokanneal_worker_task(self._h))
 
     def state(self) -> State:
         s = State()
@@ -290,7 +383,7 @@ class TokenGenerator:
         seed >= 0 with threads = 1 is reproducible."""
         states = (State * (pass_cnt + 1))()
         n = C.c_uint64()
-        _check(self._lib.tokanneal_generate(self._h, pass_cnt, threads, seed, states, pass_cnt + 1, C.byref(n)))
+        self._checked(self._lib.tokanneal_generate(self._h, pass_cnt, threads, seed, states, pass_cnt + 1, C.byref(n)))
         return [states[i] for i in range(int(n.value))]
 
     def GetSolution(self):
@@ -310,7 +403,7 @@ class TokenGenerator:
 
 def anneal_and_score(corpus, doc_off, score_corpus=None, score_off=None, max_len=10, pref_token_count=30000,
                      pass_cnt=20, batch_size=None, threads=0, seed=-1, solution_path=None, device=0,
-                     trajectory=None, gpu_candidates=False):
+                     trajectory=None, gpu_candidates=False, evaluator=None):
     """main.cpp:20-46 end to end: GetTokens(max_len) -> TokenGenerator(pref) -> Generate(pass_cnt)
     -> GetSolution -> SolutionFile(solution, path) -> score of a shard.  The shard that is scored
     defaults to the one the candidates came from.  -> (SolutionFile, counts, total_tokens,
@@ -320,12 +413,20 @@ def anneal_and_score(corpus, doc_off, score_corpus=None, score_off=None, max_len
     what the GPU measures for the solution as it stands ({"pass", "score", "enabled_cnt",
     "total_tokens", "bytes_per_token"}) -- the reference only ever sees its DAG estimate.  The
     passes then run as pass_cnt + 1 calls of Generate(0) (worker k of pass p seeded seed + p + k).
-    gpu_candidates: build the candidate set on the GPU (GetTokensGpu) instead of the host."""
+    gpu_candidates: build the candidate set on the GPU (GetTokensGpu) instead of the host.
+    evaluator="gpu": every move is judged by its exact effect on the token count of the shard the
+    candidates came from (GpuMoveEvaluator) instead of by the DAG estimate (TokenGenerator.cpp:87);
+    one worker.  The default is the reference's DAG path."""
     from . import Scorer
     from .files import SolutionFile
     sc, so = (corpus, doc_off) if score_corpus is None else (score_corpus, score_off)
     tokens = GetTokensGpu(corpus, doc_off, max_len, device) if gpu_candidates else GetTokens(corpus, doc_off, max_len)
-    gen = TokenGenerator(tokens, pref_token_count, batch_size)
+    judge = None
+    if evaluator == "gpu":
+        judge = GpuMoveEvaluator(tokens, corpus, doc_off, device)
+    elif evaluator is not None:
+        raise ValueError("evaluator must be None or 'gpu'")
+    gen = TokenGenerator(tokens, pref_token_count, batch_size, evaluator=judge)
     if trajectory is None:
         gen.Generate(pass_cnt, threads, seed)
     else:
@@ -340,6 +441,8 @@ def anneal_and_score(corpus, doc_off, score_corpus=None, score_off=None, max_len
         probe.close()
     solution = gen.GetSolution()
     gen.close()
+    if judge is not None:
+        judge.close()
     sol = SolutionFile(solution, solution_path or os.devnull, device=device)
     s = sol.scorer()
     s.set_corpus(sc, so)

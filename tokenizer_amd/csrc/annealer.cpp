@@ -1,6 +1,8 @@
 // annealer.cpp -- see annealer.h.  Host code, no GPU involved.
 #include "annealer.h"
 
+#include <stdexcept>
+
 #include <algorithm>
 #include <cmath>
 #include <thread>
@@ -187,19 +189,31 @@ size_t TokenGenerator::RunBatch(size_t work_cnt, double *samples, WorkerRng &rng
 		__builtin_prefetch(&c_.lpar[l]);
 		__builtin_prefetch(&c_.rpar[r]);
 	}
+	// with an evaluator the whole batch is judged in one call, every move against the state as it
+	// stands now (the reference's workers also judge against a state other moves are changing)
+	std::vector<double> judged;
+	if (eval_.evaluate && working->size() > first) {
+		judged.resize(working->size() - first);
+		if (!eval_.evaluate(working->data() + first, judged.size(), Enable, judged.data()))
+			throw std::runtime_error("move evaluator failed");
+	}
 	for (size_t k = first; k < working->size(); k++) {
 		const uint32_t cand = (*working)[k];
 		const size_t cnt = enabled_cnt_;
 		const double raw = raw_score_;
 		const double score = CalcScore(raw, cnt);
 
-		const double delta = SimulateStep(cand);
+		const double delta = judged.empty() ? SimulateStep(cand) : judged[k - first];
 		const double new_score = CalcScore(raw + (Enable ? delta : -delta), cnt + (Enable ? 1 : -1));
 
 		// accepted with the logistic probability of the score change at the current temperature
 		const bool do_step = rng.chance(rng.gen) > 1 / (1 + std::exp((new_score - score) / temp_));
 		if (do_step) {
-			const double applied = ApplyStep(cand, Enable);
+			double applied = ApplyStep(cand, Enable);
+			if (!judged.empty()) {
+				applied = delta; // (the DAG only follows; WorkerTask puts the exact score in after the batch)
+				if (eval_.applied && !eval_.applied(cand, Enable)) throw std::runtime_error("move evaluator failed");
+			}
 			raw_score_ += Enable ? applied : -applied;
 			enabled_cnt_ += Enable ? 1 : -1;
 		}
@@ -230,6 +244,11 @@ void TokenGenerator::WorkerTask(WorkerRng &rng) {
 	if (enable_cnt > 0) drawn_on = RunBatch<true>(enable_cnt, samples.data(), rng, &working);
 	if (enable_cnt < batch_size_) drawn_off = RunBatch<false>(batch_size_ - enable_cnt, samples.data() + enable_cnt, rng, &working);
 
+	if (eval_.resync) {
+		double raw = 0;
+		if (!eval_.resync(&raw)) throw std::runtime_error("move evaluator failed");
+		raw_score_ = raw;
+	}
 	{
 		// the sampled deltas feed the fit of the score distribution (TokenGenerator.cpp:136-146);
 		// a slot no candidate was drawn for is skipped (the reference would read stack garbage)
@@ -273,6 +292,7 @@ void TokenGenerator::Generate(size_t pass_cnt, unsigned threads, int64_t seed,
 	if (threads == 0)
 		threads = (unsigned)std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), tot_cand_ / batch_size_);
 	threads = std::max(1u, threads);
+	if (eval_.evaluate) threads = 1; // one GPU context behind the evaluator
 	const size_t tasks_per_pass = (tot_cand_ + batch_size_ - 1) / batch_size_; // `i * batch_size_ < tot_cand_`
 	std::vector<WorkerRng> rngs;
 	for (unsigned k = 0; k < threads; k++) rngs.emplace_back(seed < 0 ? std::random_device()() : (uint32_t)(seed + k));

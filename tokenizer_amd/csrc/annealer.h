@@ -60,6 +60,20 @@ struct GeneratorState { // what Generate prints after every pass (TokenGenerator
 	double moment1, moment2, beta, sigma;
 };
 
+// What judges a move instead of Token::SimulateStep's estimate on the DAG (TokenGenerator.cpp:87)
+// when one is set: the corpus itself (tokscore_score_toggles).  Values are in the raw score's own
+// unit, tokens the corpus is shorter by with the candidate enabled.
+struct MoveEvaluator {
+	// delta[k] >= 0 mostly: what candidate cand[k] is worth -- tokens saved by enabling it
+	// (enable) or lost by disabling it -- each judged alone against the state as it stands
+	std::function<bool(const uint32_t *cand, size_t n, bool enable, double *delta)> evaluate;
+	// an accepted move
+	std::function<bool(uint32_t cand, bool enable)> applied;
+	// after a batch: the exact raw score of the state as it now is (the moves of a batch were
+	// judged independently, so the sum of their deltas is not it)
+	std::function<bool(double *raw_score)> resync;
+};
+
 class TokenGenerator {
 public:
 	// TokenGenerator(std::vector<Token>&&, pref_token_count, batch_size) (TokenGenerator.cpp:17-49)
@@ -77,6 +91,12 @@ public:
 
 	// One WorkerTask (TokenGenerator.cpp:107-158) on the calling thread.
 	void WorkerTask(WorkerRng &rng);
+
+	// Moves judged by `e` from now on (an empty one: by the DAG again).  The DAG is still kept up
+	// to date by every accepted move (GetSolution orders by it).  One worker thread only; a
+	// callback that fails makes WorkerTask / Generate throw std::runtime_error.
+	void SetEvaluator(MoveEvaluator e) { eval_ = std::move(e); }
+	bool has_evaluator() const { return (bool)eval_.evaluate; }
 
 	// Generate (TokenGenerator.cpp:174-188): passes 0 .. pass_cnt INCLUSIVE (`pass <= pass_cnt`),
 	// ceil(tot_cand / batch) WorkerTasks each, on `threads` workers (0 = as the reference:
@@ -122,6 +142,7 @@ private:
 
 	std::mutex dist_mutex_;
 	LomaxDist score_dist_;
+	MoveEvaluator eval_;
 
 	std::atomic<size_t> gen_cnt_{0};
 };

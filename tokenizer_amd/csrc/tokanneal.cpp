@@ -225,6 +225,21 @@ int tokanneal_seed(tokanneal_gen *g, uint32_t seed) {
 	return TOKANNEAL_OK;
 }
 
+int tokanneal_set_evaluator(tokanneal_gen *g, tokanneal_evaluate_fn evaluate, tokanneal_applied_fn applied,
+                            tokanneal_resync_fn resync, void *user) {
+	if (!g) return TOKANNEAL_E_ARG;
+	MoveEvaluator e;
+	if (evaluate) {
+		e.evaluate = [=](const uint32_t *cand, size_t n, bool enable, double *delta) {
+			return evaluate(user, cand, (uint64_t)n, enable ? 1 : 0, delta) == 0;
+		};
+		if (applied) e.applied = [=](uint32_t cand, bool enable) { return applied(user, cand, enable ? 1 : 0) == 0; };
+		if (resync) e.resync = [=](double *raw) { return resync(user, raw) == 0; };
+	}
+	g->gen->SetEvaluator(std::move(e));
+	return TOKANNEAL_OK;
+}
+
 int tokanneal_worker_task(tokanneal_gen *g) {
 	if (!g) return TOKANNEAL_E_ARG;
 	if (g->gen->State().tot_cand == 0) return TOKANNEAL_E_DATA;
