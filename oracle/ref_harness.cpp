@@ -162,6 +162,35 @@ static int cmd_score(int argc, char **argv) {
 	return 0;
 }
 
+// text: SolutionFile::Detokenize / Prettify (SolutionFile.cpp:102-118) of every document's ids,
+// hex-encoded (the strings may hold any byte).
+static int cmd_text(int argc, char **argv) {
+	if (argc < 5) return 2;
+	SolutionFile tkn(argv[2]);
+	DataFile shard(argv[3]);
+	if (!((JsonFile &)tkn).IsValid() || !shard.IsValid()) return 3;
+	auto hex = [](const std::string &s) {
+		static const char *d = "0123456789abcdef";
+		std::string h;
+		for (unsigned char c : s) h += d[c >> 4], h += d[c & 15];
+		return h;
+	};
+	std::ofstream out(argv[4]);
+	out << "{\"detokenize_hex\": [";
+	std::vector<std::string> pretty;
+	bool first = true;
+	for (const DataFile::Entry &e : shard.GetEntries()) {
+		const std::vector<size_t> ids = tkn.Tokenize(e.text);
+		out << (first ? "" : ", ") << '"' << hex(tkn.Detokenize(ids)) << '"';
+		pretty.push_back(hex(tkn.Prettify(ids)));
+		first = false;
+	}
+	out << "],\n \"prettify_hex\": [";
+	for (size_t i = 0; i < pretty.size(); i++) out << (i ? ", " : "") << '"' << pretty[i] << '"';
+	out << "]}\n";
+	return 0;
+}
+
 // Generate() aborts as soon as stdin is readable (TokenGenerator.cpp:186);
 // park fd 0 on a pipe whose write end stays open so it never is.
 static void silence_stdin() {
@@ -338,6 +367,7 @@ int main(int argc, char **argv) {
 	if (cmd == "cands") return cmd_cands(argc, argv);
 	if (cmd == "trace") return cmd_trace(argc, argv);
 	if (cmd == "load") return cmd_load(argc, argv);
+	if (cmd == "text") return cmd_text(argc, argv);
 	std::cerr << "unknown command " << cmd << std::endl;
 	return 2;
 }

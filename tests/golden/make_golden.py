@@ -101,6 +101,22 @@ def gen_cands():
     print("cands_mixed candidates=%d docs=%d" % (len(j["tokens"]), len(texts)))
 
 
+TEXT_CASES = ["ascii_caps", "cjk_unknown", "dup_tokens", "nul_doc", "short_docs", "upper_token", "prefix_greedy"]
+
+
+def gen_text():
+    # SolutionFile::Detokenize / Prettify (SolutionFile.cpp:102-118) of every document's ids, for
+    # the small cases as they stand (ref_harness `text`); hex because a token may hold any byte.
+    for name in TEXT_CASES:
+        d = os.path.join(HERE, name)
+        out = os.path.join(d, "text.json")
+        subprocess.run([HARNESS, "text", os.path.join(d, "tokens.json"), os.path.join(d, "shard.json"), out], check=True)
+        j = json.load(open(out))
+        with open(out, "w") as f:
+            json.dump(j, f, separators=(",", ":"))
+        print("%-18s text of %d documents" % (name, len(j["detokenize_hex"])))
+
+
 def gen_anneal():
     # (14) f2 / f4: GetTokens' own `.candidates-all-5.bin` (WriteTokens) for a small mixed shard, and
     # a single-threaded, seeded run of TokenGenerator::WorkerTask on it: the state after every
@@ -229,6 +245,7 @@ def main():
 
     gen_cands()
     gen_anneal()
+    gen_text()
 
 
 if __name__ == "__main__":
@@ -236,5 +253,7 @@ if __name__ == "__main__":
         gen_cands()
     elif sys.argv[1:] == ["anneal"]:
         gen_anneal()
+    elif sys.argv[1:] == ["text"]:
+        gen_text()
     else:
         main()

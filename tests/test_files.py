@@ -215,3 +215,22 @@ def test_shard_reader_equals_datafile_on_a_synthetic_shard(tmp_path):
         c2, o2 = s.packed()
         want = [t.encode("utf-8") for t in texts]
         assert int(o2[-1]) == sum(len(w) for w in want) and c2.tobytes() == b"".join(want)
+
+
+@pytest.mark.parametrize("case", ["ascii_caps", "cjk_unknown", "dup_tokens", "nul_doc", "short_docs", "upper_token",
+                                  "prefix_greedy"])
+def test_detokenize_and_prettify_equal_the_reference(case):
+    """SolutionFile::Detokenize / Prettify (SolutionFile.cpp:102-118) on the ids the compiled
+    reference's Tokenize returned (expected.json), against what the compiled reference made of them
+    (text.json, written by tests/golden/make_golden.py text)."""
+    d = os.path.join(GOLDEN, case)
+    tkn = files.SolutionFile(os.path.join(d, "tokens.json"))
+    assert tkn.IsValid()
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    text = json.load(open(os.path.join(d, "text.json")))
+    assert len(exp["ids"]) == len(text["detokenize_hex"]) == len(text["prettify_hex"])
+    for ids, detok, pretty in zip(exp["ids"], text["detokenize_hex"], text["prettify_hex"]):
+        ids = [files.UNKNOWN if i < 0 else i for i in ids]
+        assert tkn.Detokenize(ids) == bytes.fromhex(detok)
+        assert tkn.Prettify(ids) == bytes.fromhex(pretty)
+    assert tkn.Prettify([0, 1]) == b"<START>|<END>" and tkn.Detokenize([]) == b""

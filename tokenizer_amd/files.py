@@ -145,6 +145,26 @@ class SolutionFile:
             return END_TOKEN
         return self.tokens[id_ - 2].decode("utf-8", errors="replace")
 
+    def _token_c_str(self, id_: int) -> bytes:
+        # GetToken hands out a C string (SolutionFile.cpp:79-81): whoever appends it stops at a NUL
+        if id_ == UNKNOWN:
+            return b"<UNKNOWN>"
+        if id_ == 0:
+            return START_TOKEN.encode()
+        if id_ == 1:
+            return END_TOKEN.encode()
+        return self.tokens[id_ - 2].split(b"\x00", 1)[0]
+
+    def Detokenize(self, ids) -> bytes:  # SolutionFile.cpp:102-108
+        """The tokens' strings back to back, <START> / <END> / <UNKNOWN> spelled out -- bytes, as the
+        reference's std::string is (a token may end inside a UTF-8 sequence)."""
+        return b"".join(self._token_c_str(i) for i in ids)
+
+    def Prettify(self, ids) -> bytes:  # SolutionFile.cpp:110-118
+        """The same with '|' between the tokens (the reference calls pop_back() on an empty string
+        for an empty id list, which is undefined: here that is the empty string)."""
+        return b"|".join(self._token_c_str(i) for i in ids)
+
     def scorer(self) -> Scorer:
         """The GPU context that holds this vocabulary (created on first use)."""
         if self._scorer is None:
