@@ -101,7 +101,29 @@ def gen_cands():
     print("cands_mixed candidates=%d docs=%d" % (len(j["tokens"]), len(texts)))
 
 
-TEXT_CASES = ["ascii_caps", "cjk_unknown", "dup_tokens", "nul_doc", "short_docs", "upper_token", "prefix_greedy"]
+def gen_invalid_utf8():
+    # rapidjson's default flags do not validate UTF-8 (JsonFile.cpp:21-27): bytes that are no UTF-8
+    # pass through tokens and article texts as they are.  Written byte by byte (json.dump could not).
+    d = os.path.join(HERE, "invalid_utf8")
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    tp, sp, ep = (os.path.join(d, n) for n in ("tokens.json", "shard.json", "expected.json"))
+    with open(tp, "wb") as f:
+        f.write(b'{"version": "0.4.0", "tokens": ["a", "b", "c", "f", "caf", "\xe9", "f\xe9", " ", "\xc3\xa9", "\xff\xfe"]}')
+    with open(sp, "wb") as f:
+        f.write(b'[{"id": "0", "text": "caf\xe9 caf\xc3\xa9", "title": "latin-1 and utf-8"},'
+                b' {"id": "1", "text": "ab\xff\xfe\xffc \x80", "title": "t\xe9"},'
+                b' {"id": "2", "text": "\xc3", "title": "cut sequence"}]')
+    subprocess.run([HARNESS, "score", tp, sp, ep, "--ids"], check=True, stdout=subprocess.DEVNULL)
+    exp = json.load(open(ep))
+    exp.pop("tokenize_seconds", None)
+    exp.pop("threads", None)
+    with open(ep, "w") as f:
+        json.dump(exp, f, separators=(",", ":"))
+    print("%-18s docs=%d bytes=%d tokens=%d" % ("invalid_utf8", exp["docs"], exp["total_bytes"], exp["total_tokens"]))
+
+
+TEXT_CASES = ["invalid_utf8", "ascii_caps", "cjk_unknown", "dup_tokens", "nul_doc", "short_docs", "upper_token", "prefix_greedy"]
 
 
 def gen_text():
@@ -245,6 +267,7 @@ def main():
 
     gen_cands()
     gen_anneal()
+    gen_invalid_utf8()
     gen_text()
 
 
@@ -255,5 +278,7 @@ if __name__ == "__main__":
         gen_anneal()
     elif sys.argv[1:] == ["text"]:
         gen_text()
+    elif sys.argv[1:] == ["invalid_utf8"]:
+        gen_invalid_utf8()
     else:
         main()

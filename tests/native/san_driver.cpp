@@ -90,6 +90,20 @@ int main(int argc, char **argv) {
 			CHECK(ReadCandidates(cut, &x) != READ_OK);
 		}
 	}
+	// a file whose token has a parent on one side only must be refused: the annealer indexes a
+	// non-root's parents without looking (SimulateStep / ApplyStep would go out of bounds)
+	{
+		CandidateSet bad = back;
+		size_t v = 0;
+		while (v < bad.size() && bad.rpar[v] == kNone) v++;
+		CHECK(v < bad.size());
+		bad.lpar[v] = kNone;
+		CHECK(!bad.Validate(&why));
+		const std::string bpath = tmp + "/san_bad.bin";
+		CHECK(WriteCandidates(bad, bpath, &why));
+		CandidateSet x;
+		CHECK(ReadCandidates(bpath, &x) != READ_OK);
+	}
 	// annealing: a few passes, then every move taken back
 	const std::vector<uint64_t> uses0 = c.uses;
 	const std::vector<uint32_t> rpar0 = c.rpar;

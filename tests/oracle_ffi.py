@@ -110,11 +110,12 @@ class OracleVocab:
 
 
 def _read_json(path):
+    # (bytes that are not UTF-8 pass through the reference's parser untouched: kept as surrogate escapes)
     if os.path.exists(path):
         with open(path, "rb") as f:
-            return json.loads(f.read().decode("utf-8"))
+            return json.loads(f.read().decode("utf-8", "surrogateescape"))
     with gzip.open(path + ".gz", "rb") as f:
-        return json.loads(f.read().decode("utf-8"))
+        return json.loads(f.read().decode("utf-8", "surrogateescape"))
 
 
 def golden_cases():
@@ -142,8 +143,8 @@ def load_golden(name):
     d = os.path.join(GOLDEN, name)
     tj = _read_json(os.path.join(d, "tokens.json"))
     assert tj["version"] == "0.4.0"
-    tokens = [t.encode("utf-8") for t in tj["tokens"]]
-    docs = [e["text"].encode("utf-8").split(b"\0")[0] for e in _read_json(os.path.join(d, "shard.json"))]
+    tokens = [t.encode("utf-8", "surrogateescape") for t in tj["tokens"]]
+    docs = [e["text"].encode("utf-8", "surrogateescape").split(b"\0")[0] for e in _read_json(os.path.join(d, "shard.json"))]
     exp = _read_json(os.path.join(d, "expected.json"))
     V = len(tokens)
     counts = np.zeros(V + 3, dtype=np.uint64)

@@ -234,3 +234,50 @@ def test_detokenize_and_prettify_equal_the_reference(case):
         assert tkn.Detokenize(ids) == bytes.fromhex(detok)
         assert tkn.Prettify(ids) == bytes.fromhex(pretty)
     assert tkn.Prettify([0, 1]) == b"<START>|<END>" and tkn.Detokenize([]) == b""
+
+
+def test_bytes_that_are_not_utf8_pass_through_like_in_the_reference(tmp_path):
+    """rapidjson's default flags do not validate UTF-8 (JsonFile.cpp:21-27): the invalid_utf8 golden
+    is a valid shard and a valid tokens file for the compiled reference (expected.json holds what it
+    tokenized), so it must be for the Python mirrors and the C++ shard reader, byte for byte."""
+    d = os.path.join(GOLDEN, "invalid_utf8")
+    shard = files.DataFile(os.path.join(d, "shard.json"))
+    assert shard.IsValid()
+    texts = [e.text for e in shard.GetEntries()]
+    assert texts == [b"caf\xe9 caf\xc3\xa9", b"ab\xff\xfe\xffc \x80", b"\xc3"]
+    assert shard.GetEntries()[1].title == b"t\xe9"
+    exp = json.load(open(os.path.join(d, "expected.json")))
+    assert sum(len(t) for t in texts) == exp["total_bytes"]
+    fast = files.ShardFile(os.path.join(d, "shard.json"))
+    assert fast.IsValid() and _same_entries(fast, shard)
+    tkn = files.SolutionFile(os.path.join(d, "tokens.json"))
+    assert tkn.IsValid() and tkn.tokens[5] == b"\xe9" and tkn.tokens[9] == b"\xff\xfe" and tkn.tokens[8] == "é".encode()
+    assert tkn.GetId(b"f\xe9") == 8
+    # written back, the bytes are the same again (rapidjson's Writer does not validate either)
+    out = tmp_path / "again.tokens.json"
+    again = files.SolutionFile(tkn.tokens, str(out))
+    assert files.SolutionFile(str(out)).tokens == tkn.tokens
+    again.close()
+    tkn.close()
+
+
+@pytest.mark.parametrize("text,valid", [
+    (b'[{"id":"1","title":"t","text":"\\ud834\\udd1e"}]', True),       # a pair
+    (b'[{"id":"1","title":"t","text":"\\ud834"}]', False),               # high alone
+    (b'[{"id":"1","title":"t","text":"\\udd1e x"}]', False),             # low alone
+    (b'[{"id":"1","title":"t","text":"\\ud834\\u0041"}]', False),        # high + something else
+    (b'[{"id":"1","title":"t","text":"\\\\ud834"}]', True),              # an escaped backslash, then text
+    (b'[{"id":"1","title":"t","text":"\xed\xb2\x80"}]', True),            # raw bytes are not looked at
+])
+def test_surrogate_escapes_are_judged_like_rapidjson(tmp_path, text, valid):
+    p = tmp_path / "s.json"
+    p.write_bytes(text)
+    assert files.DataFile(str(p)).IsValid() is valid
+    assert files.ShardFile(str(p)).IsValid() is valid
+
+
+def test_a_document_nested_too_deep_is_invalid_not_an_exception(tmp_path):
+    p = tmp_path / "deep.json"
+    p.write_bytes(b"[" * 200_000 + b"]" * 200_000)
+    assert files.DataFile(str(p)).IsValid() is False
+    assert files.SolutionFile(str(p)).IsValid() is False

@@ -57,6 +57,8 @@ CONFIGS = [
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_LDS_SLOTS": "300"},   # most trie lookups fall through to L2
     {"TOKSCORE_SCAN": "generic", "TOKSCORE_CHUNK": "64", "TOKSCORE_NOSNAP": "1"},  # boundaries left mid-token: fix-up kernels
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "300", "TOKSCORE_NOSNAP": "1"},
+    {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "300", "TOKSCORE_TILE_BLOCKS": "8"},   # fewer workgroups than queue heads (a small partition)
+    {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "2048", "TOKSCORE_TILE_BLOCKS": "1"},
     {"TOKSCORE_SCAN": "stream"},                               # one byte stream per lane, trie image in LDS (the default)
     {"TOKSCORE_SCAN": "stream", "TOKSCORE_STREAM": "64", "TOKSCORE_SPC": "3"},    # shortest streams, ragged chunks
     {"TOKSCORE_SCAN": "stream", "TOKSCORE_STREAM": "1000", "TOKSCORE_WAVES": "4"},
@@ -203,7 +205,7 @@ def test_toggle_equals_full_rescore_of_the_toggled_vocabulary(path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("case", ["ascii_caps", "dup_tokens", "nul_doc", "cjk_unknown"])
+@pytest.mark.parametrize("case", ["ascii_caps", "dup_tokens", "nul_doc", "cjk_unknown", "invalid_utf8"])
 def test_reference_flow_through_file_mirrors(case):
     """main.cpp:26-46 as the reference writes it: SolutionFile + DataFile + Tokenize per
     article, against what the compiled reference printed for the same two files."""

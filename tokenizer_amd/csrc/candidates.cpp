@@ -128,6 +128,14 @@ bool CandidateSet::Validate(std::string *why) const {
 		if (why) *why = "arrays of different length";
 		return false;
 	}
+	// a token is a root on both sides or on neither (Trie.cpp:145-146): the annealer indexes a
+	// non-root's two parents without looking
+	for (size_t i = 0; i < n; i++) {
+		if ((lpar[i] == kNone) != (rpar[i] == kNone)) {
+			if (why) *why = "a token with a parent on one side only";
+			return false;
+		}
+	}
 	// each chain (l and r) has to end: walk every token once, a walk that meets itself is a cycle
 	for (int side = 0; side < 2; side++) {
 		const std::vector<uint32_t> &par = side ? rpar : lpar;

@@ -428,7 +428,9 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	unsigned long long prof_t = PROF_NOW();
 	const unsigned long long prof_start = prof_t;
 	(void)prof_acc, (void)prof_t, (void)prof_start;
-	const uint32_t queue = blockIdx.x % kWorkQueues;
+	// (a grid smaller than kWorkQueues -- a partition that reports few CUs -- serves as many heads as it has workgroups)
+	const uint32_t n_queues = gridDim.x < kWorkQueues ? gridDim.x : kWorkQueues;
+	const uint32_t queue = blockIdx.x % n_queues;
 	const uint32_t n_work = sel_list ? sel_count[0] : S.nchunks; // chunks in the queue
 	const uint32_t min_seg = 4 * (((max_len + 4 + 3) / 4) | 1u); // shortest legal lane segment
 	constexpr int kMaxVec = 7; // register prefetch depth: up to 7 x 16 B per lane
@@ -436,11 +438,11 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 
 	for (;;) {
 		// ---- next work chunk ----
-		// work queue sharded over kWorkQueues heads (one 128-byte line each): chunk j belongs
-		// to head j % kWorkQueues, workgroup b pulls from head b % kWorkQueues
+		// work queue sharded over n_queues heads (one 128-byte line each): chunk j belongs
+		// to head j % n_queues, workgroup b pulls from head b % n_queues
 		uint32_t j = 0;
 		if (lane == 0) j = atomicAdd(&Qd.cursor[kQueueHeadWord + queue * kQueueHeadStride], 1u);
-		j = __builtin_amdgcn_readfirstlane(j) * kWorkQueues + queue;
+		j = __builtin_amdgcn_readfirstlane(j) * n_queues + queue;
 		if (j >= n_work) break;
 		if (sel_list) j = sel_list[j]; // incremental re-score: the queue runs over the selected chunks only
 		PROF_ADD(0, prof_t); // queue
@@ -686,7 +688,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			PROF_ADD(5, prof_t); // rest of phase 2: take-back, dual walk, round control
 			// ---- carry into the next tile / chunk exit ----
 			const unsigned long long ne = __ballot(nonempty);
-			const uint32_t last = 63u - (uint32_t)__builtin_clzll(ne); // lane 0 is always non-empty
+			const uint32_t last = ne ? 63u - (uint32_t)__builtin_clzll(ne) : 0u; // (no lane has bytes: a chunk whose begin was moved to the corpus end)
 			chunk_exit = __shfl(cur_exit, last, 64);
 			carry = chunk_exit;
 			a0 += span_c;
@@ -866,6 +868,7 @@ bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num
 	uint32_t per_cu = 1;
 	if (const char *s = getenv("TOKSCORE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(s));
 	plan->blocks = num_cus * per_cu;
+	if (const char *e = getenv("TOKSCORE_TILE_BLOCKS")) plan->blocks = (uint32_t)std::max(1, atoi(e)); // tests: a small grid
 	plan->wide_ids = wide;
 	return true;
 }

@@ -16,6 +16,7 @@ read or does not validate leaves the object with IsValid() == False, nothing is 
 (libtokscore.so); there is no CPU path in here.
 """
 import json
+import re
 import os
 
 import numpy as np
@@ -65,19 +66,48 @@ def _finite_float(text):  # kParseErrorNumberTooBig: a number that does not fit 
     return v
 
 
+_ESCAPE = re.compile(r"\\(?:u([0-9a-fA-F]{4})|.)", re.S)
+
+
+def _surrogate_escapes_paired(text: str) -> bool:
+    """rapidjson rejects a \\uD800-\\uDBFF escape that is not followed by a \\uDC00-\\uDFFF one, and a
+    low one on its own (kParseErrorStringUnicodeSurrogateInvalid); Python's json lets both through."""
+    pos = 0
+    while True:
+        m = _ESCAPE.search(text, pos)
+        if not m:
+            return True
+        pos = m.end()
+        if m.group(1) is None:
+            continue
+        cp = int(m.group(1), 16)
+        if 0xDC00 <= cp <= 0xDFFF:
+            return False
+        if 0xD800 <= cp <= 0xDBFF:
+            low = _ESCAPE.match(text, pos)
+            if not low or low.group(1) is None or not 0xDC00 <= int(low.group(1), 16) <= 0xDFFF:
+                return False
+            pos = low.end()
+
+
 def _load_json(path):
+    """The document as rapidjson's default flags read it (JsonFile.cpp:21-27): UTF-8 is NOT validated,
+    bytes that are not UTF-8 pass through strings as they are (here as surrogate escapes, which _utf8
+    turns back into the same bytes).  None for whatever rapidjson rejects or cannot be read."""
     try:
         with open(path, "rb") as f:
-            return json.loads(f.read().decode("utf-8"), object_pairs_hook=_first_wins, parse_constant=_no_constant,
-                              parse_float=_finite_float)
-    except (OSError, ValueError):
+            text = f.read().decode("utf-8", errors="surrogateescape")
+        if not _surrogate_escapes_paired(text):
+            return None
+        return json.loads(text, object_pairs_hook=_first_wins, parse_constant=_no_constant, parse_float=_finite_float)
+    except (OSError, ValueError, RecursionError):  # (rapidjson's own parser is iterative; a document nested too deep for this one is given up on)
         return None
 
 
 def _utf8(s: str):
     try:
-        return s.encode("utf-8")
-    except UnicodeEncodeError:  # lone surrogate: rapidjson rejects the file (JsonFile.cpp:26)
+        return s.encode("utf-8", errors="surrogateescape")
+    except UnicodeEncodeError:  # a lone surrogate that is not an escaped byte
         return None
 
 
@@ -124,10 +154,11 @@ class SolutionFile:
         return all(isinstance(t, str) for t in doc["tokens"])
 
     def _build_doc(self):  # SolutionFile.cpp:27-41 + JsonFile::Save (JsonFile.cpp:35-46)
-        body = ", ".join(_json_string(t.decode("utf-8")) for t in self.tokens)
+        # (rapidjson's Writer copies bytes >= 0x80 as they are, valid UTF-8 or not)
+        body = ", ".join(_json_string(t.decode("utf-8", "surrogateescape")) for t in self.tokens)
         text = '{\n    "version": %s,\n    "tokens": [%s]\n}' % (_json_string(BUILD_VERSION), body)
         with open(self.path_, "wb") as f:
-            f.write(text.encode("utf-8"))
+            f.write(text.encode("utf-8", "surrogateescape"))
 
     def IsValid(self) -> bool:
         return self.valid_
