@@ -57,7 +57,8 @@ int tokscore_device_count(void);
 int tokscore_create(tokscore_ctx **out, int device);
 void tokscore_destroy(tokscore_ctx *ctx);
 
-/* Human-readable text for a status code / the last failure inside ctx. */
+/* Human-readable text for a status code / the last failure inside ctx (ctx = NULL: why the last
+ * tokscore_create on this thread failed). */
 const char *tokscore_strerror(int status);
 const char *tokscore_last_error(const tokscore_ctx *ctx);
 

@@ -95,3 +95,26 @@ def test_toggle_on_host_trie_promotes_duplicates():
     assert s.hosttrie_longest(b"abc") == (3, 5)
     s.toggle(1, True)
     assert s.hosttrie_longest(b"abx") == (2, 3)
+
+
+def test_every_build_command_compiles_device_code_for_gfx950():
+    """What broke round 1's one-command build: with `-x c++` anywhere on its line hipcc drops
+    --offload-arch and builds the device code for its default (gfx906), so the library holds no
+    gfx950 code object and the first launch fails.  The commands the Makefile runs must all say
+    gfx950 to the device compiler (the driver's own plan, nothing is compiled here)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "tokenizer_amd", "csrc")
+    dry = subprocess.run(["make", "-C", csrc, "-n", "-B", "all", "single"], capture_output=True, text=True, check=True).stdout
+    dry = dry.replace("\\\n", " ")
+    cmds = [ln.strip() for ln in dry.splitlines() if "hipcc" in ln and ".hip" in ln]
+    assert len(cmds) >= 7, dry
+    for cmd in cmds:
+        assert "-x c++" not in cmd, cmd
+        r = subprocess.run(cmd.split() + ["-###"], capture_output=True, text=True, cwd=csrc)
+        archs = set(re.findall(r"mcpu=(gfx\w+)", r.stderr + r.stdout))
+        assert archs == {"gfx950"}, (cmd, archs)

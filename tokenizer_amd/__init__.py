@@ -14,7 +14,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtokscore.so")
+# TOKSCORE_LIBRARY: another build of the same library (csrc/Makefile `single`), for build checks
+LIB_PATH = os.environ.get("TOKSCORE_LIBRARY") or os.path.join(_HERE, "libtokscore.so")
 
 OK = 0
 E_ARG, E_NO_DEVICE, E_HIP, E_STATE, E_VOCAB, E_CAPACITY, E_INTERNAL = 1, 2, 3, 4, 5, 6, 7
@@ -113,7 +114,8 @@ class Scorer:
             self._lib.tokscore_create(C.byref(self._h), device)
         if st != OK:
             self._h = None
-            raise TokscoreError(st, self._lib.tokscore_strerror(st).decode())
+            why = self._lib.tokscore_last_error(None).decode()
+            raise TokscoreError(st, self._lib.tokscore_strerror(st).decode() + (": " + why if why else ""))
         self.V = 0
         self._keep = []
 

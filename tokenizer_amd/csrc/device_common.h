@@ -44,6 +44,34 @@ struct ChunkState {
 	uint32_t nchunks;
 };
 
+// ---- helpers every kernel file uses: defined once, here ----
+#define LDS_AS __attribute__((address_space(3)))
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS is in order per wave; this only stops the compiler moving LDS accesses across.
+__device__ __forceinline__ void wave_sync() {
+	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+// A wave-uniform value (a count, a lane mask) that the compiler does not recognise as such.
+__device__ __forceinline__ uint32_t uni32(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ unsigned long long uni64(unsigned long long x) {
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
+	const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
+	return ((unsigned long long)hi << 32) | lo;
+}
+// A-Z -> a-z on four packed bytes (bytes >= 0x80 untouched).
+__device__ __forceinline__ uint32_t lower4(uint32_t x) {
+	const uint32_t low7 = x & 0x7F7F7F7Fu;
+	const uint32_t ge_A = low7 + 0x3F3F3F3Fu; // bit7 set iff low7 >= 'A' (0x41)
+	const uint32_t gt_Z = low7 + 0x25252525u; // bit7 set iff low7 >  'Z' (0x5A)
+	const uint32_t is_up = ge_A & ~gt_Z & ~x & 0x80808080u;
+	return x | (is_up >> 2); // + 0x20
+}
+// first byte of a UTF-8 sequence (utf8/core.h:134-147)
+__device__ __forceinline__ bool is_lead(uint32_t c) { return (c & 0xC0u) != 0x80u; }
+
 // std::tolower on unsigned char in the "C" locale: only A-Z (SolutionFile.cpp:87-88).
 __device__ __forceinline__ uint32_t lower8(uint32_t c) { return c + (((c - 65u) < 26u) ? 32u : 0u); }
 

@@ -25,10 +25,6 @@ namespace tokscore {
 
 namespace {
 
-#define LDS_AS __attribute__((address_space(3)))
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr uint32_t kCountTile = 1024;            // corpus bytes owned by one tile (one wave)
 constexpr uint32_t kCountThreads = 1024;
 constexpr uint32_t kCountWaves = kCountThreads / 64;
@@ -36,13 +32,6 @@ constexpr uint32_t kPosPerLane = kCountTile / 64;
 constexpr uint32_t kCountHeadStride = 32;        // queue heads one 128-byte line apart
 constexpr uint32_t kNoLim = 0x7FFFFFFFu;
 constexpr int kPreVec = 2;                       // register prefetch: 2 x 16 B per lane = 2 KiB
-
-__device__ __forceinline__ bool is_lead(uint32_t c) { return (c & 0xC0u) != 0x80u; } // utf8/core.h:134-147
-
-__device__ __forceinline__ void wave_sync() {
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-}
 
 // next document start strictly after pos (tile relative), searched up to `stop`
 __device__ __forceinline__ uint32_t next_start(const LDS_AS uint32_t *bm, uint32_t pos, uint32_t stop) {
@@ -77,7 +66,7 @@ __global__ void __launch_bounds__(1024) count_all_kernel(TrieDev T, CorpusDev C,
                                                          uint32_t id_lo, uint32_t nbins, uint32_t n_ids,
                                                          uint32_t *heads, uint32_t ntiles, const uint64_t *tile_first,
                                                          uint32_t *slab, uint32_t with_positions, uint64_t readable_end) {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	extern __shared__ __attribute__((aligned(16))) unsigned char count_smem[];
 	__shared__ uint32_t s_positions;
 	const uint32_t tid = threadIdx.x;
 	const uint32_t lane = tid & 63;
@@ -86,7 +75,7 @@ __global__ void __launch_bounds__(1024) count_all_kernel(TrieDev T, CorpusDev C,
 	const uint32_t n_vec = cap / 16;
 	const uint32_t bm_words = cap / 32 + 1;
 	const uint32_t region = n_vec * 16 + ((bm_words * 4 + 15) & ~15u);
-	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)smem;
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)count_smem;
 	LDS_AS u32x2 *ltrie = (LDS_AS u32x2 *)lds;
 	LDS_AS uint8_t *tile = (LDS_AS uint8_t *)(lds + T.lds_slots * 8 + wave * region);
 	LDS_AS uint32_t *bitmap = (LDS_AS uint32_t *)(tile + n_vec * 16);

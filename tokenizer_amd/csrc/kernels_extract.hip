@@ -196,7 +196,7 @@ __global__ void iota_kernel(uint32_t *v, uint32_t N) {
 __global__ __launch_bounds__(kThreads) void lcp_kernel(const uint8_t *bytes, const uint64_t *win, const uint32_t *perm, uint32_t N,
                                                         uint32_t words, uint8_t *lcp, uint8_t *slen, uint32_t *inv, uint32_t *fresh,
                                                         uint64_t *srec) {
-	extern __shared__ uint64_t tile[]; // [0 .. words) rows of key words, row `words` = records
+	extern __shared__ uint64_t extract_rows[]; // [0 .. words) rows of key words, row `words` = records
 	const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
 	const uint32_t t = threadIdx.x;
 	uint64_t rb = 0;
@@ -205,23 +205,23 @@ __global__ __launch_bounds__(kThreads) void lcp_kernel(const uint8_t *bytes, con
 		rb = win[b];
 		inv[b] = (uint32_t)i;
 		srec[i] = rb;
-		for (uint32_t w = 0; w < words; w++) tile[w * kThreads + t] = window_word(bytes, rb, w);
+		for (uint32_t w = 0; w < words; w++) extract_rows[w * kThreads + t] = window_word(bytes, rb, w);
 	}
-	tile[words * kThreads + t] = rb;
+	extract_rows[words * kThreads + t] = rb;
 	__syncthreads();
 	if (i >= N) return;
 	const uint32_t lb = win_cps(rb), nb = win_bytes(rb);
 	slen[i] = (uint8_t)lb;
 	uint32_t common = 0;
 	if (i > 0) {
-		const uint64_t ra = t ? tile[words * kThreads + t - 1] : win[perm[i - 1]];
+		const uint64_t ra = t ? extract_rows[words * kThreads + t - 1] : win[perm[i - 1]];
 		const uint32_t na = win_bytes(ra);
 		const uint32_t n = na < nb ? na : nb;
 		// common bytes, a word at a time (a window that ended reads as zeros, a document holds no zero byte)
 		uint32_t same = n;
 		for (uint32_t w = 0; 8 * w < n; w++) {
-			const uint64_t A = t ? tile[w * kThreads + t - 1] : window_word(bytes, ra, w);
-			const uint64_t x = A ^ tile[w * kThreads + t];
+			const uint64_t A = t ? extract_rows[w * kThreads + t - 1] : window_word(bytes, ra, w);
+			const uint64_t x = A ^ extract_rows[w * kThreads + t];
 			if (x) {
 				const uint32_t at = 8 * w + (uint32_t)(__builtin_clzll(x) >> 3);
 				same = at < n ? at : n;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kThreads) void lcp_kernel(const uint8_t *bytes, con
 		for (uint32_t w = 0; 8 * w <= same && same > 0; w++) {
 			const uint32_t lo = w == 0 ? 1 : 8 * w, hi = same < 8 * w + 7 ? same : 8 * w + 7;
 			if (lo > hi) continue;
-			const uint64_t B = w < words ? tile[w * kThreads + t] : 0;
+			const uint64_t B = w < words ? extract_rows[w * kThreads + t] : 0;
 			const uint64_t y = (B ^ 0x8080808080808080ull) & 0xC0C0C0C0C0C0C0C0ull; // zero byte = continuation byte
 			const uint64_t starts = (y | (y >> 1)) & 0x4040404040404040ull;
 			const uint32_t qlo = lo - 8 * w, qhi = hi - 8 * w; // byte 0 is the most significant

@@ -40,30 +40,6 @@ namespace tokscore {
 
 namespace {
 
-#define LDS_AS __attribute__((address_space(3)))
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ void wave_fence() {
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-}
-__device__ __forceinline__ uint32_t uni32(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
-__device__ __forceinline__ unsigned long long uni64(unsigned long long x) {
-	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
-	const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-	return ((unsigned long long)hi << 32) | lo;
-}
-
-// A-Z -> a-z on four packed bytes (bytes >= 0x80 untouched).
-__device__ __forceinline__ uint32_t lower4(uint32_t x) {
-	const uint32_t low7 = x & 0x7F7F7F7Fu;
-	const uint32_t ge_A = low7 + 0x3F3F3F3Fu;
-	const uint32_t gt_Z = low7 + 0x25252525u;
-	const uint32_t is_up = ge_A & ~gt_Z & ~x & 0x80808080u;
-	return x | (is_up >> 2);
-}
-
 // ---- prepared corpus ---------------------------------------------------------------------
 // prep[off[d] + d .. off[d+1] + d) = document d lower-cased, prep[off[d+1] + d] = 0.  One thread
 // per 16 output bytes.  flags[0] != 0 afterwards: some document holds a NUL byte.
@@ -148,16 +124,16 @@ struct WaveLog {
 			// cannot happen: the stream is sized for one entry per prepared byte; reported all the same
 			if (batch >= S.capacity_batches && lane == 0) S.cursor[1] = 1u;
 		}
-		wave_fence();
+		wave_sync();
 		if (batch < S.capacity_batches) {
 			const LDS_AS u32x4 *src = (const LDS_AS u32x4 *)cells;
 			u32x4 *dst = reinterpret_cast<u32x4 *>(S.blocks) + ((size_t)batch * kStreamBatch + used) * vecs;
 			for (uint32_t i = lane; i < vecs; i += 64) dst[i] = src[i];
 		}
 		used++;
-		wave_fence();
+		wave_sync();
 		clear(lane);
-		wave_fence();
+		wave_sync();
 	}
 	__device__ __forceinline__ void finish(const StreamDev &S, uint32_t lane) {
 		if (cur != 0) flush(S, lane);
@@ -271,7 +247,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 		bool active = beg < end;
 		uint32_t cp = beg, lend = beg, lslot = 0, nb = 0; // (the root's base is 0)
 		uint32_t fill = beg & ~15u;
-		wave_fence();
+		wave_sync();
 		if (active) {
 #pragma unroll
 			for (uint32_t k = 0; k < RING / 16; k++) {
@@ -280,7 +256,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 				fill += 16;
 			}
 		}
-		wave_fence();
+		wave_sync();
 		bool req = false;
 		u32x4 data = {0, 0, 0, 0};
 		unsigned long long act = __builtin_amdgcn_ballot_w64(active);
@@ -292,7 +268,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 			}
 			req = active && (fill - lend) <= RING - 16;
 			if (req) data = *reinterpret_cast<const u32x4 *>(W.prep + fill);
-			wave_fence();
+			wave_sync();
 			// ---- kRound lookups ----
 			for (uint32_t it = 0; it < kRound; it++) {
 				bool done = false;
@@ -556,7 +532,7 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 				}
 			}
 		}
-		wave_fence();
+		wave_sync();
 		if (__builtin_amdgcn_ballot_w64(active) == 0) {
 			if (next >= stop) break;
 			continue;
@@ -568,7 +544,7 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 		}
 		req = active && (fill - lend) <= RING - 16;
 		if (req) data = *reinterpret_cast<const u32x4 *>(W.prep + fill);
-		wave_fence();
+		wave_sync();
 		for (uint32_t it = 0; it < kRound; it++) {
 			if (active) {
 				const uint32_t c = ring[cp & (RING - 1)];
@@ -757,7 +733,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 		bool active = cp < end;
 		uint32_t lend = cp, lslot = 0, nb = 0; // (the root's base is 0)
 		uint32_t fill = cp & ~7u;
-		wave_fence();
+		wave_sync();
 		if (active) {
 #pragma unroll
 			for (uint32_t k = 0; k < RING / 8; k++) {
@@ -766,7 +742,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 				fill += 8;
 			}
 		}
-		wave_fence();
+		wave_sync();
 		if constexpr (K != 0) {
 			const uint32_t ring_a = (uint32_t)(uintptr_t)ring;
 			const uint32_t tb = (uint32_t)((size_t)wb * rows * 64 + lane * 8); // (the transposed copy is below 4 GiB)
@@ -796,7 +772,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 				}
 				req = active && (fill - lend) <= RING - 8;
 				if (req) data = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
-				wave_fence();
+				wave_sync();
 				for (uint32_t it = 0; it < round; it++) {
 					bool done = false;
 					if (active) {

@@ -29,19 +29,7 @@ namespace tokscore {
 
 namespace {
 
-#define LDS_AS __attribute__((address_space(3)))
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr uint32_t kNoLimit = 0x7FFFFFFFu;
-
-// A wave-uniform 64-bit value (a lane mask) that the compiler does not recognise as such.
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long x) {
-	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)x);
-	const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(x >> 32));
-	return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ uint32_t uniform32(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
 
 // LDS pointers are 32-bit byte addresses; the walk keeps its positions as such addresses so
 // that a byte read needs no address arithmetic.
@@ -49,21 +37,6 @@ __device__ __forceinline__ uint32_t lds_addr(const LDS_AS void *p) { return (uin
 template <class T> __device__ __forceinline__ LDS_AS T *lds_ptr(uint32_t a) { return (LDS_AS T *)(uintptr_t)a; }
 constexpr uint32_t kLogDepth = 8; // stream entries per lane per log block
 constexpr uint32_t kPendDepth = 16; // first tokens of a lane's speculative chain remembered for the repair
-
-__device__ __forceinline__ void wave_sync() {
-	// LDS is in order per wave; this only stops the compiler moving LDS accesses across.
-	__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-}
-
-// A-Z -> a-z on four packed bytes (bytes >= 0x80 untouched).
-__device__ __forceinline__ uint32_t lower4(uint32_t x) {
-	const uint32_t low7 = x & 0x7F7F7F7Fu;
-	const uint32_t ge_A = low7 + 0x3F3F3F3Fu; // bit7 set iff low7 >= 'A' (0x41)
-	const uint32_t gt_Z = low7 + 0x25252525u; // bit7 set iff low7 >  'Z' (0x5A)
-	const uint32_t is_up = ge_A & ~gt_Z & ~x & 0x80808080u;
-	return x | (is_up >> 2); // + 0x20
-}
 
 template <bool WIDE> struct QTraits;
 template <> struct QTraits<false> {
@@ -317,9 +290,9 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	             : [cp] "+v"(wk.cp), [nb] "+v"(wk.nb), [lend] "+v"(wk.lend), [lid] "+v"(wk.lid),   \
 	               [pw] "+v"(pa_w), [mlo] "+v"(mask_lo), [mhi] "+v"(mask_hi), [act] "=&s"(act_out),   \
 	               [cur] "=&s"(cur_out), [stall] "=&s"(stall)                                         \
-	             : [lim] "v"(lim_a), [hi] "v"(hi_a), [seg] "v"(seg_a), [curin] "s"(uniform32(log.cur)), \
+	             : [lim] "v"(lim_a), [hi] "v"(hi_a), [seg] "v"(seg_a), [curin] "s"(uni32(log.cur)), \
 	               [logb] "s"(log_a),                                                              \
-	               [pwend] "v"(pend_end), [actin] "s"(uniform64(act)), [ldsb] "s"(lds_trie_bytes), \
+	               [pwend] "v"(pend_end), [actin] "s"(uni64(act)), [ldsb] "s"(lds_trie_bytes), \
 	               [trie] "s"(W.g_trie), [unk] "s"(W.unknown_id), [root] "s"(W.root_base)          \
 	             : "v24", "v25", "v26", "v27", "s38", "s39", "s40", "s41", "s42", "s43", "vcc",    \
 	               "scc", "memory")
@@ -354,8 +327,8 @@ __device__ __forceinline__ bool walk_step(const WaveCtx &W, Walker &w, uint32_t 
 	               [act] "=&s"(act_out), [merged] "+s"(merged_m), [cur] "=&s"(cur_out),             \
 	               [stall] "=&s"(stall)                                                            \
 	             : [lim] "v"(lim_a), [fasthi] "v"(fast_hi), [seg] "v"(seg_a),                      \
-	               [curin] "s"(uniform32(log.cur)), [logb] "s"(log_a),                             \
-	               [mlo] "v"(mask_lo), [mhi] "v"(mask_hi), [actin] "s"(uniform64(act)),                \
+	               [curin] "s"(uni32(log.cur)), [logb] "s"(log_a),                             \
+	               [mlo] "v"(mask_lo), [mhi] "v"(mask_hi), [actin] "s"(uni64(act)),                \
 	               [ldsb] "s"(lds_trie_bytes),                                                     \
 	               [trie] "s"(W.g_trie), [unk] "s"(W.unknown_id), [root] "s"(W.root_base)          \
 	             : "v24", "v25", "v26", "v27", "s38", "s39", "s40", "s41", "s42", "s43", "vcc",    \
@@ -386,10 +359,10 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
                                                          uint32_t halo_bytes, uint32_t max_len, uint32_t wave_lds_bytes,
                                                          uint64_t readable_end, const uint32_t *sel_list, const uint32_t *sel_count) {
 	using Q = QTraits<WIDE>;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	extern __shared__ __attribute__((aligned(16))) unsigned char tile_smem[];
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)smem;
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)tile_smem;
 
 	// ---- stage the hot trie slots in LDS (shared by the workgroup's waves) ----
 	{
@@ -410,7 +383,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 	log.init((LDS_AS typename Q::entry_t *)(wbase + n_vec * 16 + ((bm_words * 4 + 15) & ~15u)), lane);
 	// ids of the first kPendDepth tokens of every lane's speculative chain, cell (j, lane)
 	const uint32_t pend_a = lds_addr(log.cells + 64 * kLogDepth + lane);
-	const uint32_t log_a = uniform32(lds_addr(log.cells));
+	const uint32_t log_a = uni32(lds_addr(log.cells));
 	constexpr uint32_t kRow = 64 * sizeof(typename Q::entry_t);
 	const uint32_t tile_a = lds_addr(tile);
 	const uint32_t lds_trie_bytes = T.lds_slots * 8;
@@ -588,7 +561,7 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 			// limit, both handled out here (wk.lend > wk.cp tells a lane at a token start from
 			// one in the middle of a token, whose cp may legitimately have reached its limit).
 			for (unsigned long long act = __builtin_amdgcn_ballot_w64(active); act != 0;) {
-				// (the compiler takes the loop-carried mask for divergent, hence uniform64() on
+				// (the compiler takes the loop-carried mask for divergent, hence uni64() on
 				// the way in and separate in / out operands)
 				unsigned long long stall, act_out;
 				uint32_t cur_out;
@@ -718,8 +691,8 @@ template <bool WIDE>
 __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids, uint32_t range_ids, uint32_t *slab,
                                                     uint32_t flip) {
 	using Q = QTraits<WIDE>;
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	uint32_t *bins = reinterpret_cast<uint32_t *>(smem);
+	extern __shared__ __attribute__((aligned(16))) unsigned char tile_hist_smem[];
+	uint32_t *bins = reinterpret_cast<uint32_t *>(tile_hist_smem);
 	__shared__ int s_total;
 	const uint32_t lo = blockIdx.y * range_ids;
 	const uint32_t hi = lo + range_ids < n_ids ? lo + range_ids : n_ids;

@@ -929,7 +929,10 @@ const char *tokscore_strerror(int status) {
 	return "unknown status";
 }
 
-const char *tokscore_last_error(const tokscore_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+// why the last tokscore_create on this thread failed (there is no context to hold it)
+static thread_local std::string t_create_error;
+
+const char *tokscore_last_error(const tokscore_ctx *ctx) { return ctx ? ctx->err.c_str() : t_create_error.c_str(); }
 
 int tokscore_create(tokscore_ctx **out, int device) {
 	if (!out) return TOKSCORE_E_ARG;
@@ -939,32 +942,26 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	if (hipSetDevice(device) != hipSuccess) return TOKSCORE_E_NO_DEVICE;
 	tokscore_ctx *c = new tokscore_ctx();
 	c->device = device;
-	if (static_scratch_address(device, &c->static_scratch) != hipSuccess) {
+	t_create_error.clear();
+	auto give_up = [&](const char *what, hipError_t e) {
+		t_create_error = std::string(what) + ": " + hipGetErrorString(e);
 		delete c;
 		return TOKSCORE_E_HIP;
-	}
+	};
+	hipError_t e = static_scratch_address(device, &c->static_scratch);
+	if (e != hipSuccess) return give_up("address of the library's static device scratch (is the gfx950 code object loaded?)", e);
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
-	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-		delete c;
-		return TOKSCORE_E_HIP;
-	}
-	if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-	    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-		delete c;
-		return TOKSCORE_E_HIP;
-	}
-	for (auto &set : c->ring) {
-		for (auto &e : set) {
-			if (hipEventCreate(&e) != hipSuccess) {
-				delete c;
-				return TOKSCORE_E_HIP;
-			}
-		}
-	}
+	if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return give_up("stream", e);
+	if ((e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking)) != hipSuccess ||
+	    (e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+	    (e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)) != hipSuccess)
+		return give_up("stream / events", e);
+	for (auto &set : c->ring)
+		for (auto &ev : set)
+			if ((e = hipEventCreate(&ev)) != hipSuccess) return give_up("timing events", e);
 	*out = c;
 	return TOKSCORE_OK;
 }
