@@ -64,8 +64,9 @@ void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S,
 // Clears out[0 .. V+5), the stream cursor and fill words in one launch and presets
 // out[0] = out[1] = D (START / END once per document) and out[V+4] = total_bytes.
 // out == nullptr: leave the counts as they are (incremental re-score).
+// first_batches: stream batches that belong to the scan's waves from the start (scan_ranges_kernel: one per wave)
 void launch_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, const StreamDev &Q,
-                    hipStream_t stream);
+                    hipStream_t stream, uint32_t first_batches = 0);
 // counts += histogram of the token stream; out[V+3] += number of tokens counted.
 // flip: subtract what the stream adds and add what it subtracts.
 void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,

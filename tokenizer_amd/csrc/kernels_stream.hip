@@ -162,6 +162,13 @@ struct DirectLog {
 		base = reinterpret_cast<uint16_t *>(S.blocks) + (size_t)batch * kBatchEntries;
 		cur = 0;
 	}
+	// the wave's first batch is its own number: four thousand waves asking one counter at the same
+	// moment would wait for it for tens of microseconds (launch_prepare starts the counter behind them)
+	__device__ __forceinline__ void open_own(const StreamDev &S, uint32_t wave_id) {
+		batch = wave_id;
+		base = reinterpret_cast<uint16_t *>(S.blocks) + (size_t)batch * kBatchEntries;
+		cur = 0;
+	}
 	__device__ __forceinline__ void close(const StreamDev &S, uint32_t lane) {
 		if (lane == 0) S.fill[batch] = cur / 2;
 	}
@@ -715,7 +722,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 	LDS_AS unsigned char *wbase = lds + ((label_bytes + info_bytes + 127) & ~127u) + wave * (64 * RING);
 	LDS_AS unsigned char *ring = wbase + lane * RING;
 	DirectLog log;
-	log.open(Qd, lane);
+	log.open_own(Qd, blockIdx.x * waves + wave);
 
 	const uint32_t total_waves = gridDim.x * waves;
 	const uint32_t rows = W.range_bytes + W.halo; // bytes a lane's range has in its block (multiple of 8)

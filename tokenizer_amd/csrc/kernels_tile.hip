@@ -782,12 +782,12 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const uint32_t *slab, 
 
 __global__ void __launch_bounds__(256) prepare_kernel(unsigned long long *out, uint32_t V, unsigned long long D,
                                                       unsigned long long total_bytes, uint32_t *cursor, uint32_t *fill,
-                                                      uint32_t n_fill) {
+                                                      uint32_t n_fill, uint32_t first_batches) {
 	const uint32_t n = gridDim.x * blockDim.x;
 	const uint32_t i0 = blockIdx.x * blockDim.x + threadIdx.x;
 	if (out)
 		for (uint32_t i = i0; i < V + 5; i += n) out[i] = i < 2 ? D : (i == V + 4 ? total_bytes : 0ull);
-	for (uint32_t i = i0; i < kCursorWords; i += n) cursor[i] = 0;
+	for (uint32_t i = i0; i < kCursorWords; i += n) cursor[i] = i == 0 ? first_batches : 0u; // [0]: batches handed out
 	for (uint32_t i = i0; i < n_fill; i += n) fill[i] = 0;
 }
 
@@ -870,9 +870,9 @@ void launch_scan_tile(const TrieDev &T, const CorpusDev &C, const ChunkState &S,
 }
 
 void launch_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, const StreamDev &Q,
-                    hipStream_t stream) {
+                    hipStream_t stream, uint32_t first_batches) {
 	hipLaunchKernelGGL(prepare_kernel, dim3(128), dim3(256), 0, stream, out, V, (unsigned long long)D,
-	                   (unsigned long long)total_bytes, Q.cursor, Q.fill, Q.capacity_batches);
+	                   (unsigned long long)total_bytes, Q.cursor, Q.fill, Q.capacity_batches, first_batches);
 }
 
 void launch_slab_reduce(const uint32_t *slab, uint32_t rows, uint32_t n_cols, unsigned long long *counts,

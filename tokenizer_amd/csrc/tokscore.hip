@@ -606,7 +606,8 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 		c->halo = rp.halo;
 		const uint64_t nblocks = ((uint64_t)c->nranges + 63) / 64;
 		const uint64_t tbytes = nblocks * (rb + c->halo) * 64;
-		if (hipMalloc((void **)&c->d_tprep, tbytes) == hipSuccess) {
+		// (the scan addresses the transposed copy with 32-bit offsets)
+		if (tbytes < 0xFFFF0000ull && hipMalloc((void **)&c->d_tprep, tbytes) == hipSuccess) {
 			launch_transpose_ranges(c->d_prep, c->prep_total + kCorpusPad, (uint32_t)rb, c->halo, (uint32_t)nblocks, c->d_tprep, c->stream);
 			HIP_TRY(c, hipStreamSynchronize(c->stream));
 		} else {
@@ -807,7 +808,7 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	auto mark = [&](int k) -> hipError_t { return ev ? hipEventRecord(ev[k], s) : hipSuccess; };
 	if (c->scan_path == 2) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
-		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s);
+		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s, c->d_tprep ? c->rplan.blocks * c->rplan.waves_per_block : 0u);
 		HIP_TRY(c, mark(1));
 		const StreamWork W = stream_work(c, false);
 		if (c->d_tprep) launch_scan_ranges(stream_trie_dev(c), W, Q, c->rplan, s);

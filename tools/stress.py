@@ -3,7 +3,10 @@
 tests size for: a 1 GB wiki-like shard (32-bit index headroom), a CJK-heavy shard with
 single-token toggles each followed by a re-score (scaled), and a
 random-UTF-8 shard with a 128 k vocabulary (config 4, scaled; u32 stream entries).
-Usage: tools/stress.py [wiki_mb cjk_mb utf8_mb]"""
+Usage: tools/stress.py [wiki_mb cjk_mb utf8_mb]
+       tools/stress.py big [wiki_mb utf8_mb]   config 2's per-GPU share (2.5 GB wiki-like, V = 32 k) and
+                                               config 4 at full size (1.25 GB random UTF-8, V = 128 k):
+                                               one JSON record each (profiles/r02_other_configs.json)"""
 import os
 import sys
 import time
@@ -31,7 +34,87 @@ def check(name, s, voc, corpus, off, threads=16):
     return ok
 
 
+def big(name, config, tokens, corpus, off, sample_bytes=8_000_000):
+    """One shard at full per-GPU size: the first sample_bytes against the CPU oracle, then properties
+    that hold at any size -- START/END once per document, the counts add up to total_tokens,
+    total_bytes is the corpus, and a second evaluation gives the same vector.  -> a JSON record."""
+    import json
+    tb, to = synth.pack_vocab(tokens)
+    V = len(tokens)
+    D = len(off) - 1
+    voc = O.OracleVocab(tb, to)
+    d = int(np.searchsorted(off, sample_bytes, side="right")) - 1
+    d = max(d, 1)
+    s = ta.Scorer(0)
+    s.set_vocab(tb, to)
+    s.set_corpus(corpus[:int(off[d])], off[:d + 1])
+    got = s.score()
+    exp = voc.score(corpus[:int(off[d])], off[:d + 1], threads=16)
+    sample_ok = bool(np.array_equal(got[0], exp[0]) and got[1:] == exp[1:])
+    t0 = time.time()
+    s.set_corpus(corpus, off)
+    t1 = time.time()
+    counts, tt, tby = s.score()
+    first_s = time.time() - t1
+    info = s.info()
+    evals = []
+    again = None
+    for _ in range(5):
+        again = s.score()
+        evals.append(s.last_timing())
+    tm = [float(np.median([e[k] for e in evals])) for k in range(4)]
+    props = {"start_end_once_per_document": bool(int(counts[0]) == D and int(counts[1]) == D),
+             "counts_add_up_to_total_tokens": bool(int(counts[2:].sum()) == tt),
+             "total_bytes_is_the_corpus": bool(tby == int(off[-1])),
+             "second_evaluation_identical": bool(np.array_equal(again[0], counts) and again[1:] == (tt, tby))}
+    # incremental re-score and batched moves at this size: one rare token off and on again
+    rare = int(np.argmin(np.where(counts[2:2 + V] > 0, counts[2:2 + V], np.iinfo(np.int64).max)))
+    delta = int(s.score_toggles([rare], [0])[0])
+    s.toggle(rare, False)
+    inc = s.score(incremental=True)
+    resc = int(s.info().rescored_chunks)
+    s.toggle(rare, True)
+    back = s.score(incremental=True)
+    props["toggle_delta_equals_incremental_rescore"] = bool(inc[1] - tt == delta)
+    props["toggled_back_identical"] = bool(np.array_equal(back[0], counts) and back[1] == tt)
+    rec = {"config": config, "bytes": int(tby), "docs": D, "vocab": V, "trie_slots": int(info.trie_slots),
+           "lds_slots": int(info.trie_lds_slots), "scan_path": int(info.scan_path), "chunks": int(info.chunks),
+           "total_tokens": int(tt), "set_corpus_s": t1 - t0, "first_evaluation_s": first_s,
+           "eval_ms": tm[0], "scan_ms": tm[1], "fixup_ms": tm[2], "hist_reduce_ms": tm[3],
+           "GBps_eval": tby / tm[0] / 1e6 if tm[0] else 0.0, "sample_bytes": int(off[d]), "sample_parity": sample_ok,
+           "rare_token_rescored_chunks": resc, **props}
+    s.close()
+    print(json.dumps(rec), flush=True)
+    return sample_ok and all(props.values())
+
+
+def main_big(wiki_mb, utf8_mb):
+    import threading
+    t_start = time.time()
+
+    def heartbeat():  # (generating gigabytes of text takes minutes: say so)
+        while True:
+            time.sleep(45)
+            print("  ... %.0f s" % (time.time() - t_start), file=sys.stderr, flush=True)
+    threading.Thread(target=heartbeat, daemon=True).start()
+    ok = True
+    if wiki_mb > 0:
+        src, _ = synth.wiki_like(2_000_000, seed=20201120)
+        tokens = synth.build_vocab(src, 32000)
+        corpus, off = synth.wiki_like(int(wiki_mb * 1e6), seed=20201120)
+        ok &= big("wiki", "config 2 per-GPU share: wiki-like %.0f MB, V=32k" % wiki_mb, tokens, corpus, off)
+        del corpus
+    if utf8_mb > 0:
+        corpus, off = synth.random_utf8(int(utf8_mb * 1e6), seed=355)
+        tokens = synth.sample_vocab(corpus[: 50_000_000], 128000)
+        ok &= big("utf8", "config 4: random UTF-8 %.0f MB, V=128k sampled from the corpus" % utf8_mb, tokens, corpus, off)
+    print("ALL OK" if ok else "MISMATCH")
+    sys.exit(0 if ok else 1)
+
+
 def main():
+    if sys.argv[1:2] == ["big"]:
+        return main_big(*[float(x) for x in (sys.argv[2:4] + ["2500", "1250"][len(sys.argv) - 2:])])
     wiki_mb, cjk_mb, utf8_mb = [float(x) for x in (sys.argv[1:4] + ["1000", "200", "200"][len(sys.argv) - 1:])]
     allok = True
     # 1. large wiki-like shard
