@@ -125,3 +125,26 @@ def test_empty_and_invalid_arguments():
             s.score_toggles([2], [0])
     finally:
         s.close()
+
+
+def test_incremental_rescore_on_the_default_cost_model(monkeypatch):
+    """Without TOKSCORE_INCR_DIV the library chooses between two partial passes and a full
+    evaluation by estimated cost (a small corpus: always the full evaluation): the result is the
+    same either way."""
+    monkeypatch.delenv("TOKSCORE_INCR_DIV", raising=False)
+    corpus, off = synth.wiki_like(800_000, seed=33)
+    tokens = synth.build_vocab(corpus[:300_000], 3000)
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        s.score()
+        enabled = np.ones(len(tokens), dtype=bool)
+        for i in (len(tokens) // 2, len(tokens) // 3):
+            enabled[i] = False
+            s.toggle(i, False)
+            got = s.score(incremental=True)
+            assert got[1] == _oracle_total(tokens, enabled, corpus, off)
+            assert s.info().rescored_chunks == 0xFFFFFFFF, "a full evaluation was expected to be cheaper here"
+    finally:
+        s.close()

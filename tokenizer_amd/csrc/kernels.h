@@ -125,6 +125,8 @@ struct ToggleBatch {
 	unsigned long long *items;  // [kToggleLists][cap_items] scratch: (move, stream) for every stream the string occurs in
 	uint32_t *n_items;          // [kToggleLists] items per list, zeroed by the launcher
 	uint32_t cap_items;         // per list
+	uint32_t *seen = nullptr;   // optional, one bit per stream, zeroed by the caller: a stream is listed once
+	                            // whichever moves' strings occur in it (incremental re-score)
 };
 struct StreamScanPlan {
 	uint32_t ring;            // bytes of a lane's LDS ring

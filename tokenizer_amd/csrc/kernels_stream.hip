@@ -227,13 +227,27 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 
 	const uint32_t total_lanes = gridDim.x * waves * 64;
 	const uint32_t gl = (blockIdx.x * waves + wave) * 64 + lane;
-	uint32_t n_items;
-	if (W.sel_list) n_items = W.sel_count[0] * W.streams_per_chunk; // incremental re-score: the selected chunks' streams
+	uint32_t n_items, my_items = 0;
+	if (W.tg_items) {
+		// incremental re-score with the occurrence index: the streams of the kToggleLists lists
+		// (launch_find_toggle_streams), lane q walks list q (total_lanes is a multiple of 64)
+		static_assert(kToggleLists == 64, "one list per lane");
+		my_items = W.tg_count[lane] < W.tg_cap ? W.tg_count[lane] : W.tg_cap;
+		uint32_t most = my_items;
+		for (int o = 32; o > 0; o >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, o, 64));
+		n_items = most * 64;
+	} else if (W.sel_list) n_items = W.sel_count[0] * W.streams_per_chunk; // incremental re-score without the index: the selected chunks' streams
 	else n_items = W.nranges;                                       // full evaluation: equal ranges
 
 	for (uint32_t item = gl; __builtin_amdgcn_ballot_w64(item < n_items) != 0; item += total_lanes) {
 		uint32_t beg = 0, end = 0;
-		if (item < n_items) {
+		if (W.tg_items) {
+			if ((item >> 6) < my_items) {
+				const uint32_t strm = (uint32_t)W.tg_items[(size_t)lane * W.tg_cap + (item >> 6)];
+				beg = W.pbeg[strm];
+				end = W.pbeg[strm + 1];
+			}
+		} else if (item < n_items) {
 			if (W.sel_list) {
 				uint32_t s0, s1;
 				const uint32_t chunk = W.sel_list[item / W.streams_per_chunk];
@@ -250,7 +264,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 				beg += W.entry[item]; // (may lie at or past `end`: the chain jumps the whole range)
 			}
 		}
-		const bool has_range = !W.sel_list && item < n_items;
+		const bool has_range = !W.tg_items && !W.sel_list && item < n_items;
 		bool active = beg < end;
 		uint32_t cp = beg, lend = beg, lslot = 0, nb = 0; // (the root's base is 0)
 		uint32_t fill = beg & ~15u;
@@ -399,6 +413,18 @@ __global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B
 	}
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 	__builtin_amdgcn_wave_barrier();
+	if (B.seen) {
+		// a stream another pair (another move, another wave) listed already is not listed again
+		for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
+			const uint32_t i = i0 + lane;
+			if (i < ns && ((s_bits[wave][i >> 5] >> (i & 31)) & 1u)) {
+				const uint32_t sidx = s0 + i, bit = 1u << (sidx & 31);
+				if (atomicOr(&B.seen[sidx >> 5], bit) & bit) atomicAnd(&s_bits[wave][i >> 5], ~(1u << (i & 31)));
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	}
 	{
 		uint32_t n = lane < 16 ? (uint32_t)__builtin_popcount(s_bits[wave][lane]) : 0u;
 		for (int o = 8; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);

@@ -146,6 +146,8 @@ struct tokscore_ctx {
 	size_t tg_pairs_cap = 0;
 	unsigned long long *d_tg_items = nullptr;
 	size_t tg_items_cap = 0;
+	uint32_t *d_tg_seen = nullptr; // one bit per stream: listed already (incremental re-score)
+	size_t tg_seen_cap = 0;
 	uint32_t *d_stream_tokens = nullptr; // [nstreams] tokens per stream, valid while stream_tokens_epoch == trie_epoch
 	size_t stream_tokens_cap = 0;
 	uint64_t trie_epoch = 1, stream_tokens_epoch = 0; // trie_epoch: another one whenever the device trie or the plan changes
@@ -904,6 +906,92 @@ int check_overflow(tokscore_ctx *c) { // after fetch_out
 	return TOKSCORE_OK;
 }
 
+// One batch of (token, index row, stream-image slot) for the search of the streams the tokens'
+// strings occur in (launch_find_toggle_streams): the description goes to the device in one blob,
+//   delta[n] (u64, zero) | items per list [kToggleLists] (zero) | rows[n] | pair_off[n+1] | slots[n] | str_off[n+1] | codes
+// and the scratch buffers grow to what the batch can need.  dedupe: every stream listed once
+// whichever tokens occur in it (incremental re-score); otherwise once per token (independent moves).
+struct ToggleSpec {
+	uint64_t token;
+	uint32_t row, slot, chunks;
+};
+struct ToggleUpload {
+	ToggleBatch B;
+	uint64_t pairs = 0, list_cap = 0;
+	const uint32_t *d_slots = nullptr;
+	unsigned long long *d_delta = nullptr;
+};
+int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool dedupe, hipStream_t s, ToggleUpload *up) {
+	const uint64_t per_chunk = c->widest_chunk; // no chunk has more streams (plan_stream)
+	uint64_t pairs = 0;
+	for (uint32_t k = 0; k < n; k++) pairs += m[k].chunks;
+	if (pairs > 0xFFFFFFF0ull / per_chunk / 2) return fail(c, TOKSCORE_E_CAPACITY, "a toggled token touches too many streams for one launch");
+	// items: kToggleLists lists; list q takes what the workgroups q, q + kToggleLists, .. of the search find
+	// (16 pairs per workgroup), so this many entries per list always suffice
+	const uint64_t find_blocks = (pairs + 15) / 16;
+	const uint64_t list_cap = std::max<uint64_t>(1, (find_blocks + kToggleLists - 1) / kToggleLists * 16 * per_chunk);
+	const uint64_t cap_items = list_cap * kToggleLists;
+	std::vector<uint32_t> meta((size_t)2 * n + kToggleLists, 0);
+	std::vector<uint8_t> codes;
+	const size_t rows_at = meta.size();
+	for (uint32_t k = 0; k < n; k++) meta.push_back(m[k].row);
+	const size_t poff_at = meta.size();
+	uint32_t acc = 0;
+	for (uint32_t k = 0; k < n; k++) {
+		meta.push_back(acc);
+		acc += m[k].chunks;
+	}
+	meta.push_back(acc);
+	const size_t slots_at = meta.size();
+	for (uint32_t k = 0; k < n; k++) meta.push_back(m[k].slot);
+	const size_t soff_at = meta.size();
+	for (uint32_t k = 0; k < n; k++) {
+		meta.push_back((uint32_t)codes.size());
+		for (uint64_t i = c->h_vocab_off[m[k].token]; i < c->h_vocab_off[m[k].token + 1]; i++) codes.push_back(c->simg.code[c->h_vocab_bytes[i]]);
+	}
+	meta.push_back((uint32_t)codes.size());
+	const size_t codes_at = meta.size() * sizeof(uint32_t);
+	const size_t blob = codes_at + ((codes.size() + 15) & ~(size_t)15) + 16;
+	auto grow = [&](void **p, size_t *cap, size_t need, size_t elem) -> hipError_t {
+		if (need <= *cap) return hipSuccess;
+		if (*p) (void)hipFree(*p);
+		*p = nullptr, *cap = 0;
+		const hipError_t e = hipMalloc(p, need * elem);
+		if (e == hipSuccess) *cap = need;
+		return e;
+	};
+	HIP_TRY(c, grow((void **)&c->d_tg_meta, &c->tg_meta_cap, blob * 2, 1));
+	HIP_TRY(c, grow((void **)&c->d_tg_pairs, &c->tg_pairs_cap, std::max<uint64_t>(1, pairs), sizeof(uint32_t)));
+	HIP_TRY(c, grow((void **)&c->d_tg_items, &c->tg_items_cap, cap_items, sizeof(unsigned long long)));
+	const size_t seen_words = ((size_t)c->nstreams + 31) / 32 + 1;
+	if (dedupe) {
+		HIP_TRY(c, grow((void **)&c->d_tg_seen, &c->tg_seen_cap, seen_words, sizeof(uint32_t)));
+		HIP_TRY(c, hipMemsetAsync(c->d_tg_seen, 0, seen_words * sizeof(uint32_t), s));
+	}
+	// (pageable source: the copy has left the host buffer when the call returns)
+	HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta, meta.data(), codes_at, hipMemcpyHostToDevice, s));
+	if (!codes.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta + codes_at, codes.data(), codes.size(), hipMemcpyHostToDevice, s));
+	uint32_t *words = (uint32_t *)c->d_tg_meta;
+	ToggleBatch &B = up->B;
+	B.n = n;
+	B.index = c->d_index;
+	B.words_per_row = (c->nchunks + 31) / 32;
+	B.rows = words + rows_at;
+	B.pair_off = words + poff_at;
+	B.str_off = words + soff_at;
+	B.codes = c->d_tg_meta + codes_at;
+	B.pairs = c->d_tg_pairs;
+	B.items = c->d_tg_items;
+	B.n_items = words + 2 * n;
+	B.cap_items = (uint32_t)list_cap;
+	B.seen = dedupe ? c->d_tg_seen : nullptr;
+	up->pairs = pairs;
+	up->list_cap = list_cap;
+	up->d_slots = words + slots_at;
+	up->d_delta = (unsigned long long *)c->d_tg_meta;
+	return TOKSCORE_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -993,6 +1081,7 @@ void tokscore_destroy(tokscore_ctx *c) {
 		if (c->d_tg_meta) (void)hipFree(c->d_tg_meta);
 		if (c->d_tg_pairs) (void)hipFree(c->d_tg_pairs);
 		if (c->d_tg_items) (void)hipFree(c->d_tg_items);
+		if (c->d_tg_seen) (void)hipFree(c->d_tg_seen);
 		if (c->d_stream_tokens) (void)hipFree(c->d_stream_tokens);
 		if (c->h_patch) (void)hipHostFree(c->h_patch);
 		for (auto &set : c->ring)
@@ -1213,12 +1302,26 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 			c->ev = view;
 		}
 		bool listed = false; // d_sel_list holds the selected chunks
+		bool streams_listed = false; // by_stream holds the streams to scan (no chunk list)
+		ToggleUpload by_stream;
 		auto mark = [&](int k) -> hipError_t {
 			return ev && (c->timing_detail || k == 0 || k == 4) ? hipEventRecord(ev[k], s) : hipSuccess;
 		};
 		HIP_TRY(c, mark(0));
 		if (c->index_state == 0) build_index(c);
-		const uint32_t limit = c->nchunks / (uint32_t)std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)); // beyond this two partial passes cost what a full evaluation does
+		// Two partial passes (about 0.11 ms each before the first stream is walked, then the longest
+		// selected stream decides, which grows with their number) against one full evaluation (about
+		// 0.05 ms + 0.95 ms per GB): on a 100 MB shard the full evaluation always wins, on a 1 GB
+		// shard a token in up to a thousand chunks is re-scored faster.  TOKSCORE_INCR_DIV = d: the
+		// plain rule "at most 1/d of the chunks" instead (tests).
+		uint32_t limit;
+		if (getenv("TOKSCORE_INCR_DIV")) {
+			limit = c->nchunks / (uint32_t)std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3));
+		} else {
+			const double full_us = 50.0 + 0.95e-6 * (double)c->total; // 0.95 us per MB
+			const double fixed_us = 2 * 110.0, per_chunk_us = 2 * 0.3;
+			limit = full_us > fixed_us ? (uint32_t)std::min<double>((full_us - fixed_us) / per_chunk_us, c->nchunks / 3.0) : 0u;
+		}
 		if (c->index_state == 1) {
 			// the index knows the chunks (and how many) without a search or a host sync
 			uint32_t rows[8], nrows = 0;
@@ -1235,7 +1338,23 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 				if (ev) c->calls--; // this call's event set goes to the full evaluation
 				return tokscore_score(c, counts, total_tokens, total_bytes);
 			}
-			if (nsel) launch_or_rows(c->d_index, rows, nrows, c->nchunks, c->d_sel, s);
+			if (nsel && c->scan_path == 2) {
+				// the streams the toggled strings occur in (a chunk is sixteen of them): found once,
+				// scanned by both passes
+				ToggleSpec spec[8];
+				uint32_t nspec = 0;
+				for (size_t k = 0; k < c->pending.size() && nspec < nrows; k++) {
+					const int32_t r = c->tok_row[c->pending[k].first];
+					bool seen = r < 0;
+					for (uint32_t m = 0; m < nspec; m++) seen = seen || spec[m].row == (uint32_t)r;
+					if (!seen) spec[nspec++] = ToggleSpec{c->pending[k].first, (uint32_t)r, 0u, c->row_chunks[r]};
+				}
+				int st = upload_toggle_batch(c, spec, nspec, true, s, &by_stream);
+				if (st) return st;
+				StreamWork Wf = stream_work(c, false);
+				launch_find_toggle_streams(by_stream.B, Wf, (uint32_t)by_stream.pairs, c->nchunks, s);
+				streams_listed = true;
+			} else if (nsel) launch_or_rows(c->d_index, rows, nrows, c->nchunks, c->d_sel, s);
 		} else {
 			HIP_TRY(c, hipMemsetAsync(c->d_sel, 0, ((size_t)(c->nchunks + 31) / 32 + 1) * sizeof(uint32_t), s));
 			for (size_t k = 0; k < c->pending.size(); k++) {
@@ -1259,14 +1378,20 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		// the scan hands out no more stream batches than it takes chunks, and a wave of the
 		// histogram takes whole batches (any grid is correct): no more histogram workgroups, and
 		// slab rows to add up, than that needs
-		if (nsel && !listed) launch_compact_sel(c->d_sel, c->nchunks, c->d_sel_list, s);
+		if (nsel && !listed && !streams_listed) launch_compact_sel(c->d_sel, c->nchunks, c->d_sel_list, s);
 		const uint32_t hist_blocks = std::max<uint32_t>(1, std::min<uint32_t>(c->slab_blocks, (nsel + 15) / 16));
 		HIP_TRY(c, mark(1));
 		// one partial pass: the selected chunks scanned under the device trie as it is now
 		auto partial_pass = [&](bool flip) {
 			launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s);
 			if (c->scan_path == 2) {
-				launch_scan_stream(stream_trie_dev(c), stream_work(c, true), Q, c->splan, s);
+				StreamWork Wp = stream_work(c, !streams_listed);
+				if (streams_listed) {
+					Wp.tg_items = by_stream.B.items;
+					Wp.tg_count = by_stream.B.n_items;
+					Wp.tg_cap = by_stream.B.cap_items;
+				}
+				launch_scan_stream(stream_trie_dev(c), Wp, Q, c->splan, s);
 				launch_histogram_slots(Q, (uint32_t)c->simg.lt.size(), c->d_slot_id, c->d_out, (uint32_t)c->V + 3, c->d_slab,
 				                       hist_blocks, s, flip);
 			} else {
@@ -1357,18 +1482,16 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		st = tokscore_score_incremental(c, counts.data(), nullptr, nullptr);
 		if (st) return st;
 	}
-	struct Move {
-		uint64_t k;
-		uint32_t row, slot, chunks;
-	};
-	std::vector<Move> moves;
+	std::vector<ToggleSpec> moves;
+	std::vector<uint64_t> move_k;
 	for (uint64_t k = 0; k < K; k++) {
 		delta_total_tokens[k] = 0;
 		bool flips = false;
 		const int64_t t = c->trie.PeekStream(token_index[k], enable[k] != 0, c->simg, &flips);
 		const int32_t row = c->tok_row[token_index[k]];
 		if (t < 0 || !flips || row < 0 || c->row_chunks[row] == 0) continue; // nothing in this corpus can change
-		moves.push_back(Move{k, (uint32_t)row, (uint32_t)t, c->row_chunks[row]});
+		moves.push_back(ToggleSpec{token_index[k], (uint32_t)row, (uint32_t)t, c->row_chunks[row]});
+		move_k.push_back(k);
 	}
 	if (moves.empty()) return TOKSCORE_OK;
 	// tokens per stream under the vocabulary as it is: one walk over all streams, kept until the
@@ -1386,100 +1509,37 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		HIP_TRY(c, hipGetLastError());
 		c->stream_tokens_epoch = c->trie_epoch;
 	}
-	const uint64_t per_chunk = c->widest_chunk; // no chunk has more streams (plan_stream)
 	const uint64_t budget = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 16ull << 20));
 	const StreamWork W0 = stream_work(c, false);
 	size_t first = 0;
-	std::vector<uint32_t> meta;
-	std::vector<uint8_t> codes;
 	while (first < moves.size()) {
 		// a batch: as many moves as the item budget holds (one at least)
 		size_t last = first;
 		uint64_t pairs = 0;
-		while (last < moves.size() && (last == first || (pairs + moves[last].chunks) * per_chunk <= budget)) pairs += moves[last++].chunks;
+		while (last < moves.size() && (last == first || (pairs + moves[last].chunks) * c->widest_chunk <= budget)) pairs += moves[last++].chunks;
 		const uint32_t n = (uint32_t)(last - first);
-		if (pairs > 0xFFFFFFF0ull / per_chunk / 2) return fail(c, TOKSCORE_E_CAPACITY, "score_toggles: a move touches too many streams for one launch");
-		// items: kToggleLists lists; list q takes what the workgroups q, q + kToggleLists, .. of the search find
-		// (16 pairs per workgroup), so this many entries per list always suffice
-		const uint64_t find_blocks = (pairs + 15) / 16;
-		const uint64_t list_cap = (find_blocks + kToggleLists - 1) / kToggleLists * 16 * per_chunk;
-		const uint64_t cap_items = list_cap * kToggleLists;
-		// device blob: delta[n] (u64) | items per list [kToggleLists] | rows[n] | pair_off[n+1] | slots[n] | str_off[n+1] | codes
-		meta.clear();
-		codes.clear();
-		meta.resize((size_t)2 * n + kToggleLists, 0); // delta and the item counters start at zero
-		const size_t rows_at = meta.size();
-		for (uint32_t m = 0; m < n; m++) meta.push_back(moves[first + m].row);
-		const size_t poff_at = meta.size();
-		uint32_t acc = 0;
-		for (uint32_t m = 0; m < n; m++) {
-			meta.push_back(acc);
-			acc += moves[first + m].chunks;
-		}
-		meta.push_back(acc);
-		const size_t slots_at = meta.size();
-		for (uint32_t m = 0; m < n; m++) meta.push_back(moves[first + m].slot);
-		const size_t soff_at = meta.size();
-		for (uint32_t m = 0; m < n; m++) {
-			meta.push_back((uint32_t)codes.size());
-			const uint64_t tok = token_index[moves[first + m].k];
-			for (uint64_t i = c->h_vocab_off[tok]; i < c->h_vocab_off[tok + 1]; i++) codes.push_back(c->simg.code[c->h_vocab_bytes[i]]);
-		}
-		meta.push_back((uint32_t)codes.size());
-		const size_t codes_at = meta.size() * sizeof(uint32_t);
-		const size_t blob = codes_at + ((codes.size() + 15) & ~(size_t)15) + 16;
-		if (blob > c->tg_meta_cap) {
-			if (c->d_tg_meta) (void)hipFree(c->d_tg_meta);
-			c->d_tg_meta = nullptr, c->tg_meta_cap = 0;
-			HIP_TRY(c, hipMalloc((void **)&c->d_tg_meta, blob * 2));
-			c->tg_meta_cap = blob * 2;
-		}
-		if (pairs > c->tg_pairs_cap) {
-			if (c->d_tg_pairs) (void)hipFree(c->d_tg_pairs);
-			c->d_tg_pairs = nullptr, c->tg_pairs_cap = 0;
-			HIP_TRY(c, hipMalloc((void **)&c->d_tg_pairs, pairs * sizeof(uint32_t)));
-			c->tg_pairs_cap = pairs;
-		}
-		if (cap_items > c->tg_items_cap) {
-			if (c->d_tg_items) (void)hipFree(c->d_tg_items);
-			c->d_tg_items = nullptr, c->tg_items_cap = 0;
-			HIP_TRY(c, hipMalloc((void **)&c->d_tg_items, cap_items * sizeof(unsigned long long)));
-			c->tg_items_cap = cap_items;
-		}
-		HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta, meta.data(), codes_at, hipMemcpyHostToDevice, s));
-		if (!codes.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta + codes_at, codes.data(), codes.size(), hipMemcpyHostToDevice, s));
-		uint32_t *words = (uint32_t *)c->d_tg_meta;
-		ToggleBatch B;
-		B.n = n;
-		B.index = c->d_index;
-		B.words_per_row = (c->nchunks + 31) / 32;
-		B.rows = words + rows_at;
-		B.pair_off = words + poff_at;
-		B.str_off = words + soff_at;
-		B.codes = c->d_tg_meta + codes_at;
-		B.pairs = c->d_tg_pairs;
-		B.items = c->d_tg_items;
-		B.n_items = words + 2 * n;
-		B.cap_items = (uint32_t)list_cap;
+		ToggleUpload up;
+		st = upload_toggle_batch(c, moves.data() + first, n, false, s, &up);
+		if (st) return st;
 		StreamWork W = W0;
-		W.tg_items = c->d_tg_items;
-		W.tg_count = B.n_items;
-		W.tg_cap = B.cap_items;
-		W.tg_slot = words + slots_at;
+		W.tg_items = up.B.items;
+		W.tg_count = up.B.n_items;
+		W.tg_cap = up.B.cap_items;
+		W.tg_slot = up.d_slots;
 		W.tg_base = c->d_stream_tokens;
-		W.tg_delta = (unsigned long long *)c->d_tg_meta;
-		launch_find_toggle_streams(B, W, (uint32_t)pairs, c->nchunks, s);
-		launch_walk_toggles(stream_trie_dev(c), W, c->splan, cap_items, s);
+		W.tg_delta = up.d_delta;
+		launch_find_toggle_streams(up.B, W, (uint32_t)up.pairs, c->nchunks, s);
+		launch_walk_toggles(stream_trie_dev(c), W, c->splan, up.list_cap * kToggleLists, s);
 		HIP_TRY(c, hipGetLastError());
 		std::vector<uint64_t> res((size_t)n + kToggleLists / 2);
 		HIP_TRY(c, hipMemcpyAsync(res.data(), c->d_tg_meta, res.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
 		HIP_TRY(c, hipStreamSynchronize(s));
 		const uint32_t *per_list = reinterpret_cast<const uint32_t *>(res.data() + n);
 		for (uint32_t q = 0; q < kToggleLists; q++) {
-			if (per_list[q] > B.cap_items) return fail(c, TOKSCORE_E_INTERNAL, "score_toggles: more streams than the chunks can hold");
+			if (per_list[q] > up.B.cap_items) return fail(c, TOKSCORE_E_INTERNAL, "score_toggles: more streams than the chunks can hold");
 			c->toggle_items += per_list[q];
 		}
-		for (uint32_t m = 0; m < n; m++) delta_total_tokens[moves[first + m].k] = (int64_t)res[m];
+		for (uint32_t m = 0; m < n; m++) delta_total_tokens[move_k[first + m]] = (int64_t)res[m];
 		first = last;
 	}
 	return TOKSCORE_OK;
