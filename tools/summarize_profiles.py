@@ -41,6 +41,22 @@ def main():
         pmc["hbm_read_bytes_per_launch"] = 2 * pmc["FETCH_SIZE"] * 1024   # gfx950: FETCH_SIZE counts 128-B requests as 64 B
         pmc["hbm_write_bytes_per_launch"] = pmc["WRITE_SIZE"] * 1024
         pmc["traffic_bytes_per_launch"] = pmc["hbm_read_bytes_per_launch"] + pmc["hbm_write_bytes_per_launch"]
+    # the acceptance figures of the scan's instruction diet, per corpus byte of one launch
+    alg = json.loads(line).get("roofline", {}).get("alg_bytes_per_launch")
+    if alg and "SQ_INSTS_VALU" in pmc:
+        pmc["valu_instructions_per_byte"] = pmc["SQ_INSTS_VALU"] / alg
+        pmc["salu_instructions_per_byte"] = pmc.get("SQ_INSTS_SALU", 0.0) / alg
+        pmc["lds_instructions_per_byte"] = pmc.get("SQ_INSTS_LDS", 0.0) / alg
+    if "SQ_THREAD_CYCLES_VALU" in pmc and pmc.get("SQ_ACTIVE_INST_VALU"):
+        # lanes switched on, averaged over all vector instructions (the 5 of 17 per lookup that log a
+        # finished token run with only the finishing lanes on)
+        pmc["valu_lane_utilization"] = pmc["SQ_THREAD_CYCLES_VALU"] / (64.0 * pmc["SQ_ACTIVE_INST_VALU"])
+    if "SQ_INSTS_VMEM_WR" in pmc and alg:
+        # one store instruction per lookup step of a wave: lane-steps offered per corpus byte
+        pmc["lookup_steps_per_wave_launch"] = pmc["SQ_INSTS_VMEM_WR"]
+        pmc["lane_steps_per_byte"] = 64.0 * pmc["SQ_INSTS_VMEM_WR"] / alg
+    if alg and "traffic_bytes_per_launch" in pmc:
+        pmc["traffic_over_algorithmic_bytes"] = pmc["traffic_bytes_per_launch"] / alg
     pmc["kernel"] = kernel
     json.dump(pmc, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(pmc, indent=1, sort_keys=True))
