@@ -24,11 +24,11 @@ def main():
     json.loads(line)
     open(os.path.join(dst, tag + "_bench.json"), "w").write(line + "\n")
     stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
-    if stats:
-        shutil.copy(stats[0], os.path.join(dst, tag + "_kernel_stats.csv"))
+    if stats:  # (a tag refreshed twice holds two traces: the newest one)
+        shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, tag + "_kernel_stats.csv"))
     kernel = json.loads(line).get("roofline", {}).get("kernel", "scan_tile_kernel")
     pmc = {}
-    for f in sorted(glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+    for f in sorted(glob.glob(os.path.join(src, "pmc*", "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime):
         acc = collections.defaultdict(float)
         disp = collections.defaultdict(set)
         for r in csv.DictReader(open(f)):
