@@ -137,10 +137,15 @@ struct StreamScanPlan {
 	uint32_t lds_bytes;
 };
 void launch_prep_corpus(const CorpusDev &C, const ByteCodes &M, uint8_t *prep, uint64_t prep_total, uint32_t *flags,
-                        hipStream_t stream);
+                        hipStream_t stream, bool lower = true);
 bool plan_stream_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan);
 void launch_scan_stream(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
                         hipStream_t stream);
+// Row f1 on the stream image: one stream entry (the slot the walk ended on) per code point position
+// of W.tprep, which here is the transposed prepared corpus WITHOUT lower-casing; *positions += their
+// number.  Per-slot totals: launch_histogram_slots with slot_id = nullptr.
+void launch_count_ends(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
+                       uint32_t first_cont, uint32_t max_cp, unsigned long long *positions, hipStream_t stream);
 // Batched move evaluation.  launch_find_toggle_streams: the streams each move's string occurs in
 // (B.items / B.n_items), from the occurrence index and a search of the chunks it lists;
 // launch_walk_toggles: every listed stream walked with the move's token-end bit flipped, the

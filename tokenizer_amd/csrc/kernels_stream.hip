@@ -44,7 +44,7 @@ namespace {
 // prep[off[d] + d .. off[d+1] + d) = document d lower-cased, prep[off[d+1] + d] = 0.  One thread
 // per 16 output bytes.  flags[0] != 0 afterwards: some document holds a NUL byte.
 __global__ void __launch_bounds__(256) prep_corpus_kernel(CorpusDev C, ByteCodes M, uint8_t *prep, uint64_t prep_total,
-                                                          uint32_t *flags) {
+                                                          uint32_t *flags, uint32_t lower) {
 	__shared__ uint8_t s_code[256];
 	s_code[threadIdx.x] = M.code[threadIdx.x]; // blockDim.x == 256
 	__syncthreads();
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256) prep_corpus_kernel(CorpusDev C, ByteCodes
 			if (q < dend) {
 				c = C.bytes[q - d];
 				nul = nul || c == 0;
-				c = s_code[lower8(c)];
+				c = s_code[lower ? lower8(c) : c]; // (the counting path matches bytes as they are)
 			}
 			w[k >> 2] |= c << (8 * (k & 3));
 		}
@@ -835,6 +835,119 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 	log.close(Qd, lane);
 }
 
+// ---- closed-vocabulary occurrence counting (row f1) on the stream image --------------------------
+// What ExtractCandidates + Trie::AddString add up (GetTokens.cpp:21-27, Trie.cpp:114-128): every code
+// point position of every document starts a window of up to max_cp code points, and every
+// vocabulary string that is a prefix of the window gets +1.  All those prefixes lie on ONE trie
+// path, so a position only has to say where its walk ENDED -- one stream entry per position instead
+// of one increment per prefix (4.2 per position on the bench shard) -- and the host adds every
+// slot's ends to its ancestors afterwards (VocabTrie::AccumulateEnds, 38 k nodes).  The corpus is
+// the prepared one WITHOUT lower-casing (this path matches bytes as they are), ranges, rings and
+// log as in scan_ranges_kernel.  A walk starts at every byte that starts a code point
+// (code < first_cont: trie.h) and is no separator; it stops at a miss, a leaf, a separator, or when
+// a (max_cp + 1)-th code point would start.  No range needs its neighbour: nothing to repair.
+template <uint32_t RING, uint32_t K> // K: lookups per round (W.round), unrolled
+__global__ void __launch_bounds__(1024) count_ends_kernel(StreamTrieDev T, StreamWork W, StreamDev Qd, uint32_t first_cont,
+                                                          uint32_t max_cp, unsigned long long *positions) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char count_ends_smem[];
+	__shared__ uint32_t s_positions;
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)count_ends_smem;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = uni32(threadIdx.x >> 6);
+	const uint32_t waves = blockDim.x >> 6;
+	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
+	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
+	{
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
+		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		dst = (LDS_AS u32x4 *)(lds + label_bytes);
+		src = reinterpret_cast<const u32x4 *>(T.base);
+		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		if (threadIdx.x == 0) s_positions = 0;
+	}
+	__syncthreads();
+	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
+	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
+	LDS_AS unsigned char *ring = lds + ((label_bytes + info_bytes + 127) & ~127u) + (wave * 64 + lane) * RING;
+	DirectLog log;
+	log.open_own(Qd, blockIdx.x * waves + wave);
+	const uint32_t total_waves = gridDim.x * waves;
+	const uint32_t rows = W.range_bytes + W.halo;
+	constexpr uint32_t high = kBatchEntries * 2 - 128 * K; // a round adds at most 64 K entries
+	uint32_t npos = 0;
+	for (uint32_t wb = blockIdx.x * waves + wave; wb * 64 < W.nranges; wb += total_waves) {
+		const uint32_t g = wb * 64 + lane;
+		const uint8_t *blk = W.tprep + (size_t)wb * rows * 64 + lane * 8;
+		uint32_t end = 0;
+		if (g < W.nranges) {
+			const uint32_t b = g * W.range_bytes;
+			end = b + W.range_bytes < W.prep_total ? W.range_bytes : W.prep_total - b;
+		}
+		bool active = end != 0;
+		uint32_t p = 0, d = 0, nb = 0, last = 0, ncp = 0, fill = 0;
+		wave_sync();
+		if (active) {
+#pragma unroll
+			for (uint32_t k = 0; k < RING / 8; k++) {
+				const u32x2 x = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
+				*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = x;
+				fill += 8;
+			}
+		}
+		wave_sync();
+		bool req = false;
+		u32x2 data = {0, 0};
+		unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+		while (act != 0) {
+			if (req) {
+				*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = data;
+				fill += 8;
+			}
+			req = active && (fill - p) <= RING - 8; // (nothing before p is read again)
+			if (req) data = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
+			wave_sync();
+#pragma unroll
+			for (uint32_t it = 0; it < K; it++) {
+				bool ended = false;
+				if (active) {
+					const uint32_t c = ring[(p + d) & (RING - 1)];
+					const bool lead = c < first_cont; // a code point (or the separator) starts here
+					if (d == 0 && (!lead || c == 0)) {
+						p++; // no window starts inside a code point or on a separator
+						active = p < end;
+					} else {
+						const bool stop = d != 0 && lead && (c == 0 || ncp == max_cp);
+						const uint32_t t = nb + c;
+						const uint32_t x = l_lt[t] ^ c;
+						const uint32_t b = l_base[t];
+						const bool hit = !stop && (x & 0x7Fu) == 0;
+						last = hit ? t : last;
+						d += hit ? 1u : 0u;
+						ncp += hit && lead ? 1u : 0u;
+						nb = hit ? b : 0u;
+						ended = nb == 0; // (the first byte of a window always hits: the root row is dense)
+					}
+				}
+				log.put(ended, last);
+				if (ended) {
+					npos++;
+					p++;
+					d = 0, ncp = 0;
+					active = p < end;
+				}
+			}
+			log.roll_if_full(Qd, lane, high);
+			act = __builtin_amdgcn_ballot_w64(active);
+		}
+	}
+	log.close(Qd, lane);
+	for (int o = 32; o > 0; o >>= 1) npos += __shfl_xor(npos, o, 64);
+	if (lane == 0 && npos) atomicAdd(&s_positions, npos);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_positions) atomicAdd(positions, (unsigned long long)s_positions);
+}
+
 // tprep block wb, piece k, lane l = the 8 bytes prep[(wb * 64 + l) * range_bytes + 8 k ...] (zero past
 // what is readable of the linear copy).  One thread per piece.
 __global__ void __launch_bounds__(256) transpose_ranges_kernel(const uint8_t *prep, uint64_t prep_readable, uint32_t range_bytes,
@@ -1107,7 +1220,7 @@ __global__ void __launch_bounds__(1024) slab_reduce_map_kernel(const uint32_t *s
 		atomicAdd(&out[total_index], (unsigned long long)sum);
 		return;
 	}
-	const uint32_t id = slot_id[s];
+	const uint32_t id = slot_id ? slot_id[s] : s; // (no map: counts per slot)
 	if (id == 0xFFFFFFFFu) atomicAdd(&out[total_index], (unsigned long long)(-sum));
 	else atomicAdd(&out[id], (unsigned long long)sum);
 }
@@ -1117,11 +1230,11 @@ __global__ void __launch_bounds__(1024) slab_reduce_map_kernel(const uint32_t *s
 // ---- host side -----------------------------------------------------------------------------
 
 void launch_prep_corpus(const CorpusDev &C, const ByteCodes &M, uint8_t *prep, uint64_t prep_total, uint32_t *flags,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool lower) {
 	if (prep_total == 0 || C.D == 0) return;
 	const uint64_t nvec = (prep_total + 15) / 16;
 	const uint32_t blocks = (uint32_t)std::min<uint64_t>((nvec + 255) / 256, 1u << 16);
-	hipLaunchKernelGGL(prep_corpus_kernel, dim3(blocks), dim3(256), 0, stream, C, M, prep, prep_total, flags);
+	hipLaunchKernelGGL(prep_corpus_kernel, dim3(blocks), dim3(256), 0, stream, C, M, prep, prep_total, flags, lower ? 1u : 0u);
 }
 
 bool plan_stream_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan) {
@@ -1219,6 +1332,30 @@ void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const Strea
 		else if (plan.ring == 64) go(&scan_ranges_kernel<64, 0>);
 		else go(&scan_ranges_kernel<128, 0>);
 	}
+}
+
+void launch_count_ends(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
+                       uint32_t first_cont, uint32_t max_cp, unsigned long long *positions, hipStream_t stream) {
+	auto go = [&](auto kernel) {
+		// (this kernel has a static LDS word beside the dynamic block)
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                          (int)plan.lds_bytes);
+		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, T, W, Q,
+		                   first_cont, max_cp, positions);
+	};
+	auto pick = [&](auto ring) {
+		constexpr uint32_t R = decltype(ring)::value;
+		switch (plan.round) {
+		case 4: go(&count_ends_kernel<R, 4>); break;
+		case 5: go(&count_ends_kernel<R, 5>); break;
+		case 6: go(&count_ends_kernel<R, 6>); break;
+		case 7: go(&count_ends_kernel<R, 7>); break;
+		default: go(&count_ends_kernel<R, 8>); break; // (plan_ranges_scan: 4 .. 8)
+		}
+	};
+	if (plan.ring == 32) pick(std::integral_constant<uint32_t, 32>{});
+	else if (plan.ring == 64) pick(std::integral_constant<uint32_t, 64>{});
+	else pick(std::integral_constant<uint32_t, 128>{});
 }
 
 void launch_scan_stream(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,

@@ -148,6 +148,11 @@ struct tokscore_ctx {
 	size_t tg_items_cap = 0;
 	uint32_t *d_tg_seen = nullptr; // one bit per stream: listed already (incremental re-score)
 	size_t tg_seen_cap = 0;
+	// row f1 on the stream image: the prepared corpus without lower-casing, transposed like d_tprep
+	// (built by the first tokscore_count_occurrences of a plan), per-slot totals
+	uint8_t *d_tprep_raw = nullptr;
+	unsigned long long *d_slot_ends = nullptr; // [nslots + 2]: ends per slot | entries | positions
+	size_t slot_ends_cap = 0;
 	uint32_t *d_stream_tokens = nullptr; // [nstreams] tokens per stream, valid while stream_tokens_epoch == trie_epoch
 	size_t stream_tokens_cap = 0;
 	uint64_t trie_epoch = 1, stream_tokens_epoch = 0; // trie_epoch: another one whenever the device trie or the plan changes
@@ -303,6 +308,8 @@ void free_plan(tokscore_ctx *c) {
 	c->d_range_state = nullptr;
 	if (c->d_tprep) (void)hipFree(c->d_tprep);
 	c->d_tprep = nullptr;
+	if (c->d_tprep_raw) (void)hipFree(c->d_tprep_raw);
+	c->d_tprep_raw = nullptr;
 	c->d_chunk_begin = nullptr;
 	c->d_chunk_state = nullptr;
 	c->d_stream = nullptr;
@@ -992,6 +999,76 @@ int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool d
 	return TOKSCORE_OK;
 }
 
+// tokscore_count_occurrences on the stream image: where every position's walk ended -> per-slot
+// totals -> (host) every string's subtree sum.
+int count_on_stream_image(tokscore_ctx *c, uint32_t max_cp, uint64_t *counts, uint64_t *positions) {
+	hipStream_t s = c->stream;
+	const uint32_t nslots = (uint32_t)c->simg.lt.size();
+	if (!c->d_tprep_raw) {
+		// the prepared corpus again, bytes as they are (this path does not lower-case), straight
+		// into the transposed layout; the linear copy is only needed on the way
+		uint8_t *d_raw = nullptr;
+		uint32_t *d_flags = nullptr;
+		const uint64_t nblocks = ((uint64_t)c->nranges + 63) / 64;
+		const uint64_t tbytes = nblocks * ((uint64_t)c->range_bytes + c->halo) * 64;
+		hipError_t e = hipMalloc((void **)&d_raw, c->prep_total + kCorpusPad);
+		if (e == hipSuccess) e = hipMalloc((void **)&d_flags, sizeof(uint32_t));
+		if (e == hipSuccess) e = hipMalloc((void **)&c->d_tprep_raw, tbytes);
+		if (e == hipSuccess) e = hipMemsetAsync(d_raw + (c->prep_total & ~15ull), 0, kCorpusPad + (c->prep_total & 15), s);
+		if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t), s);
+		if (e == hipSuccess) {
+			CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+			ByteCodes M;
+			memcpy(M.code, c->simg.code, 256);
+			launch_prep_corpus(C, M, d_raw, c->prep_total, d_flags, s, /*lower=*/false);
+			launch_transpose_ranges(d_raw, c->prep_total + kCorpusPad, c->range_bytes, c->halo, (uint32_t)nblocks, c->d_tprep_raw, s);
+			e = hipStreamSynchronize(s);
+		}
+		if (d_raw) (void)hipFree(d_raw);
+		if (d_flags) (void)hipFree(d_flags);
+		if (e != hipSuccess) {
+			if (c->d_tprep_raw) (void)hipFree(c->d_tprep_raw);
+			c->d_tprep_raw = nullptr;
+			return fail(c, TOKSCORE_E_HIP, std::string("count_occurrences: ") + hipGetErrorString(e));
+		}
+	}
+	if ((size_t)nslots + 2 > c->slot_ends_cap) {
+		if (c->d_slot_ends) (void)hipFree(c->d_slot_ends);
+		c->d_slot_ends = nullptr, c->slot_ends_cap = 0;
+		HIP_TRY(c, hipMalloc((void **)&c->d_slot_ends, ((size_t)nslots + 2) * sizeof(unsigned long long)));
+		c->slot_ends_cap = (size_t)nslots + 2;
+	}
+	StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
+	HIP_TRY(c, hipMemsetAsync(c->d_slot_ends, 0, ((size_t)nslots + 2) * sizeof(unsigned long long), s));
+	launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s, c->rplan.blocks * c->rplan.waves_per_block);
+	StreamWork W = stream_work(c, false);
+	W.tprep = c->d_tprep_raw;
+	// events as for an evaluation (tokscore_last_timing: [1] = the counting kernel, [3] = histogram + reduction)
+	hipEvent_t *ev = nullptr;
+	if (c->timing_on) {
+		ev = c->ring[c->calls % tokscore_ctx::kRing];
+		hipEvent_t *view = c->view[c->calls % tokscore_ctx::kRing];
+		c->calls++;
+		view[0] = view[1] = ev[1];
+		view[2] = view[3] = ev[2];
+		view[4] = ev[4];
+		c->ev = view;
+		HIP_TRY(c, hipEventRecord(ev[1], s));
+	}
+	launch_count_ends(stream_trie_dev(c), W, Q, c->rplan, c->simg.first_cont_code, max_cp, c->d_slot_ends + nslots + 1, s);
+	if (ev) HIP_TRY(c, hipEventRecord(ev[2], s));
+	launch_histogram_slots(Q, nslots, nullptr, c->d_slot_ends, nslots, c->d_slab, c->slab_blocks, s);
+	if (ev) HIP_TRY(c, hipEventRecord(ev[4], s));
+	c->timing_pending = ev != nullptr;
+	HIP_TRY(c, hipGetLastError());
+	std::vector<uint64_t> ends((size_t)nslots + 2);
+	HIP_TRY(c, hipMemcpyAsync(ends.data(), c->d_slot_ends, ends.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+	HIP_TRY(c, hipStreamSynchronize(s));
+	c->trie.AccumulateEnds(ends.data(), max_cp, counts);
+	if (positions) *positions = ends[(size_t)nslots + 1];
+	return TOKSCORE_OK;
+}
+
 } // namespace
 
 extern "C" {
@@ -1083,6 +1160,7 @@ void tokscore_destroy(tokscore_ctx *c) {
 		if (c->d_tg_items) (void)hipFree(c->d_tg_items);
 		if (c->d_tg_seen) (void)hipFree(c->d_tg_seen);
 		if (c->d_stream_tokens) (void)hipFree(c->d_stream_tokens);
+		if (c->d_slot_ends) (void)hipFree(c->d_slot_ends);
 		if (c->h_patch) (void)hipHostFree(c->h_patch);
 		for (auto &set : c->ring)
 			for (auto &e : set)
@@ -1558,6 +1636,16 @@ int tokscore_count_occurrences(tokscore_ctx *c, uint32_t max_cp, uint64_t *count
 	st = apply_pending(c, c->stream);
 	if (st) return st;
 	c->state_valid = false; // d_out is reused below
+	// On the stream image (kernels_stream.hip: count_ends_kernel) when the plan has one with
+	// transposed ranges and every token fits the walk; TOKSCORE_COUNT=tile keeps the older kernel.
+	{
+		const char *force = getenv("TOKSCORE_COUNT");
+		if (!(force && !strcmp(force, "tile")) && c->total != 0) {
+			st = ensure_plan(c);
+			if (st) return st;
+			if (c->scan_path == 2 && c->d_tprep && c->simg_valid) return count_on_stream_image(c, max_cp, counts, positions);
+		}
+	}
 	const uint32_t n_ids = (uint32_t)c->V + 3;
 	TrieDev T = trie_dev(c);
 	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};

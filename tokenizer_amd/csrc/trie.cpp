@@ -278,19 +278,31 @@ void VocabTrie::StreamSlotValues(uint32_t node, uint32_t code, uint8_t *lt, uint
 bool VocabTrie::PackStream(StreamImage *out) {
 	out->valid = false;
 	const uint32_t N = (uint32_t)first_child_.size();
-	// codes: 0 = separator (byte 0), 1..k = bytes that label an edge, k + 1 = every other byte
+	// codes: 0 = separator (byte 0); then the bytes that label an edge and can start a UTF-8 sequence,
+	// one code for every other such byte; then (from first_cont_code on) the continuation bytes
+	// 0x80-0xBF that label an edge and one code for the other continuation bytes -- so that
+	// "this byte starts a code point" is `code < first_cont_code` (the counting kernel needs it)
 	bool is_label[256] = {};
 	for (const Edge &e : edges_) is_label[e.byte] = true;
 	is_label[0] = false; // edges labelled NUL are left out
 	uint32_t k = 0;
 	for (uint32_t b = 1; b < 256; b++)
 		if (is_label[b]) k++;
-	if (k + 2 > StreamImage::kCodes) return false;
-	const uint32_t other = k + 1;
+	if (k + 3 > StreamImage::kCodes) return false;
+	uint32_t other = 0; // the largest code: every continuation byte without an edge
 	{
+		auto is_cont = [](uint32_t b) { return (b & 0xC0u) == 0x80u; };
 		uint32_t next = 1;
 		out->code[0] = 0;
-		for (uint32_t b = 1; b < 256; b++) out->code[b] = (uint8_t)(is_label[b] ? next++ : other);
+		for (uint32_t b = 1; b < 256; b++)
+			if (is_label[b] && !is_cont(b)) out->code[b] = (uint8_t)next++;
+		const uint32_t other_lead = next++;
+		out->first_cont_code = next;
+		for (uint32_t b = 0x80; b < 0xC0; b++)
+			if (is_label[b]) out->code[b] = (uint8_t)next++;
+		other = next;
+		for (uint32_t b = 1; b < 256; b++)
+			if (!is_label[b]) out->code[b] = (uint8_t)(is_cont(b) ? other : other_lead);
 	}
 	// Rows widest first (packs tightest).  The image is used only when ALL of it fits in LDS, so
 	// unlike Pack there is nothing to gain from a hot-first order.  Nodes below an edge labelled
@@ -391,8 +403,9 @@ bool VocabTrie::PackStream(StreamImage *out) {
 		const Edge *e = edges_.data() + first_child_[node];
 		codes.clear();
 		for (uint32_t i = 0; i < n_children_[node]; i++)
-			if (e[i].byte != 0) codes.push_back(out->code[e[i].byte]); // bytes ascending = codes ascending
+			if (e[i].byte != 0) codes.push_back(out->code[e[i].byte]);
 		if (codes.empty()) continue;
+		std::sort(codes.begin(), codes.end()); // (place() starts from the smallest)
 		const uint32_t b = (uint32_t)place(codes.data(), (uint32_t)codes.size());
 		node_base[node] = b;
 		for (uint32_t i = 0; i < n_children_[node]; i++)
@@ -460,6 +473,35 @@ int64_t VocabTrie::PeekStream(uint64_t token, bool enable, const StreamImage &im
 	enabled_[token] = was;
 	*flips = ((lt ^ img.lt[t]) & 0x80u) != 0;
 	return t;
+}
+
+void VocabTrie::AccumulateEnds(const uint64_t *slot_ends, uint32_t max_cp, uint64_t *counts) const {
+	(void)max_cp; // (the walks stop there by themselves: deeper nodes have no ends)
+	for (uint64_t i = 0; i < V_ + 3; i++) counts[i] = 0;
+	const uint32_t N = (uint32_t)first_child_.size();
+	if (node_sslot_.size() != N) return;
+	// UTF-8 state of every node's string: bytes still owed to the current code point, -1 = not UTF-8
+	std::vector<int8_t> owed(N, 0);
+	std::vector<uint64_t> visits(N, 0);
+	for (uint32_t n = 0; n < N; n++) { // breadth-first numbering: a parent comes before its children
+		const Edge *e = edges_.data() + first_child_[n];
+		for (uint32_t i = 0; i < n_children_[n]; i++) {
+			const uint32_t b = e[i].byte;
+			int8_t st = owed[n];
+			if (st < 0) st = -1;
+			else if (st > 0) st = (b & 0xC0u) == 0x80u ? (int8_t)(st - 1) : (int8_t)-1;
+			else st = b < 0x80u ? 0 : b >= 0xC2u && b < 0xE0u ? 1 : b >= 0xE0u && b < 0xF0u ? 2 : b >= 0xF0u && b < 0xF5u ? 3 : -1;
+			owed[e[i].child] = st;
+		}
+	}
+	for (uint32_t n = N; n-- > 0;) { // children before parents
+		if (n != 0 && node_sslot_[n]) visits[n] += slot_ends[node_sslot_[n]];
+		const Edge *e = edges_.data() + first_child_[n];
+		for (uint32_t i = 0; i < n_children_[n]; i++) visits[n] += visits[e[i].child];
+		if (n == 0 || owed[n] != 0) continue;
+		const uint32_t id = ActiveId(n);
+		if (id) counts[id] += visits[n];
+	}
 }
 
 uint32_t VocabTrie::StringRows(uint64_t nslots, std::vector<int32_t> *slot_row, std::vector<int32_t> *tok_row) const {

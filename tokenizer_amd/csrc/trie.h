@@ -64,6 +64,7 @@ struct StreamImage {
 	std::vector<uint16_t> base;
 	std::vector<uint32_t> slot_id;
 	uint8_t code[256] = {};
+	uint32_t first_cont_code = 0; // a byte starts a code point (or is a separator) iff code[byte] < first_cont_code
 	uint32_t root_base = 0;
 	bool valid = false;
 };
@@ -96,6 +97,13 @@ public:
 	// in the image (-1: none) and whether its token-end bit would flip (the only thing a toggle can
 	// change about where tokens end; the id a slot counts for does not move a boundary).
 	int64_t PeekStream(uint64_t token, bool enable, const StreamImage &img, bool *flips);
+	// Closed-vocabulary occurrence counts from "where did the walk from every position end":
+	// slot_ends[t] = walks (of at most max_cp code points, inside one document) whose deepest match
+	// is slot t of the image.  A string occurs wherever a walk reaches its node, i.e. ends there or
+	// below: counts[id] (V + 3 entries, cleared here) gets the subtree sum on the id the string's
+	// first enabled entry has (Trie.cpp:114-128 counts strings of whole code points only: an entry
+	// that is not valid UTF-8 on its own stays 0).
+	void AccumulateEnds(const uint64_t *slot_ends, uint32_t max_cp, uint64_t *counts) const;
 	bool Enabled(uint64_t token) const { return token < V_ && enabled_[token] != 0; }
 
 	// Rows of a per-string table (one row per distinct non-empty token string): slot_row[t] = row

@@ -34,9 +34,18 @@ def main():
         s.count_occurrences(max_cp)
         ts.append(time.perf_counter() - t0)
     ms = float(np.median(ts)) * 1e3
+    tm = s.last_timing()  # [1] the counting kernel, [3] histogram + reduction (the stream-image path records them)
     rec = {"metric": "corpus GB/s, closed-vocabulary all-occurrence counting (f1)", "value": len(corpus) / ms / 1e6,
            "unit": "GB/s", "ms_per_call_host_wall": ms, "bytes": int(len(corpus)), "vocab": len(tokens), "max_cp": max_cp,
            "positions": pos, "increments": int(counts.sum())}
+    if tm[1] > 0:
+        rec["kernel"] = "count_ends_kernel"
+        rec["kernel_ms"] = tm[1]
+        rec["hist_reduce_ms"] = tm[3]
+        # 1 algorithmic byte per corpus byte, one launch = the whole shard
+        rec["roofline"] = {"bound": "hbm", "achieved": len(corpus) / tm[1] / 1e6, "peak": 8000.0, "unit": "GB/s",
+                           "frac": len(corpus) / tm[1] / 1e6 / 8000.0, "traffic": None}
+
     if "--no-cpu" not in sys.argv:
         import oracle_ffi as O
         voc = O.OracleVocab(*synth.pack_vocab(tokens))
