@@ -298,12 +298,22 @@ def main():
         sys.stderr.write("bench.py: rank %d has no GPU (%d visible)\n" % (rank, torch.cuda.device_count()))
         sys.exit(2)
     dist = None
-    if world > 1:
+    # BENCH_RCCL_SELFTEST=1 (one rank): run the exchange of the N > 1 path anyway -- an RCCL
+    # communicator of one rank, the same all_reduce calls on the same stream after score_async -- so
+    # that the collective code has run on hardware at all; labelled in the line, never the headline.
+    selftest = world == 1 and os.environ.get("BENCH_RCCL_SELFTEST") == "1"
+    if world > 1 or selftest:
         import torch.distributed as dist
+        if selftest:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ranks_in_exchange = 2 if selftest else world  # (> 1: reduce_result / max_over_ranks do call the collective)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -323,15 +333,15 @@ def main():
     out = torch.zeros(V + 5, dtype=torch.int64, device=dev)  # counts | total_tokens | total_bytes
     stream = torch.cuda.current_stream()
 
-    dist_mod = dist if world > 1 else None
+    dist_mod = dist if ranks_in_exchange > 1 else None
 
     def step():
         scorer.score_async(out.data_ptr(), stream.cuda_stream)
-        reduce_result(out, dist_mod, world, host_reduce=rehearsal)
+        reduce_result(out, dist_mod, ranks_in_exchange, host_reduce=rehearsal)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if ranks_in_exchange > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -341,7 +351,7 @@ def main():
     tm = scorer.drain_timings()[-args.steps:]
     eval_ms = [t[0] for t in tm]
     scan_ms = [t[1] for t in tm]
-    elapsed = max_over_ranks(elapsed, dist_mod, world, "cpu" if rehearsal else dev)
+    elapsed = max_over_ranks(elapsed, dist_mod, ranks_in_exchange, "cpu" if rehearsal else dev)
     # what d_out cannot show: a token-stream overflow of the last asynchronous evaluation
     overflowed = scorer.async_status(stream.cuda_stream)
     if overflowed:
@@ -371,7 +381,8 @@ def main():
             "metric": "corpus GB/s scored per full-vocab eval",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else ""),
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else "")
+            + (" (RCCL SELFTEST: one rank, the all-reduce of the N > 1 path inside every step)" if selftest else ""),
             "config": {"workload": "configs[1]: wiki-like %.0f MB shard per GPU (seed 20201120+rank), "
                                    "one full-vocabulary scoring pass, V=%d" % (args.mb, V),
                        "docs_per_gpu": int(info.corpus_docs), "bytes_per_gpu": int(info.corpus_bytes),
@@ -398,7 +409,7 @@ def main():
             scorer.close()
             sys.exit(4)
     scorer.close()
-    if world > 1:
+    if ranks_in_exchange > 1:
         dist.destroy_process_group()
 
 

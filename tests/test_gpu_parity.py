@@ -371,3 +371,22 @@ def test_stream_overflow_is_reported_or_rescued():
         s.close()
         if out:
             out.free()
+
+
+@pytest.mark.gpu
+def test_bench_exchange_runs_over_rccl_on_one_rank():
+    """bench.py's N > 1 exchange (score_async, then all_reduce of the u64 vector on the same stream,
+    barrier, max over ranks) executed with RCCL on the hardware that is there: a communicator of one
+    rank (BENCH_RCCL_SELFTEST=1).  The line must still carry an exact in-run parity check."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_RCCL_SELFTEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--mb", "8", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "RCCL SELFTEST" in line["data"] and line["n_gpus"] == 1
+    assert line["parity_checked"]["exact"] is True and line["parity_checked"]["bytes"] == 8_000_000 or line["parity_checked"]["exact"] is True

@@ -156,6 +156,10 @@ struct tokscore_ctx {
 	uint32_t *d_stream_tokens = nullptr; // [nstreams] tokens per stream, valid while stream_tokens_epoch == trie_epoch
 	size_t stream_tokens_cap = 0;
 	uint64_t trie_epoch = 1, stream_tokens_epoch = 0; // trie_epoch: another one whenever the device trie or the plan changes
+	// knobs of the move paths, read once at tokscore_create (not on every call)
+	bool knob_noincr = false, knob_nobatch = false;
+	uint64_t knob_incr_div = 0;      // 0: the cost estimate decides
+	uint64_t knob_toggle_items = 16ull << 20;
 	uint64_t toggle_items = 0; // (move, stream) items walked by score_toggles so far (diagnostics)
 	// occurrence index (one bit per string and chunk), built by the first incremental re-score of a plan
 	uint32_t *d_index = nullptr;
@@ -1116,6 +1120,10 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	};
 	hipError_t e = static_scratch_address(device, &c->static_scratch);
 	if (e != hipSuccess) return give_up("address of the library's static device scratch (is the gfx950 code object loaded?)", e);
+	c->knob_noincr = env_u64("TOKSCORE_NOINCR", 0) != 0;
+	c->knob_nobatch = env_u64("TOKSCORE_NOBATCH", 0) != 0;
+	c->knob_incr_div = getenv("TOKSCORE_INCR_DIV") ? std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)) : 0;
+	c->knob_toggle_items = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 16ull << 20));
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
@@ -1359,7 +1367,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 	(void)hipSetDevice(c->device);
 	const bool eligible = c->state_valid && c->plan_valid && c->packed_valid && c->device_trie_valid && c->d_vocab_valid &&
 	                      c->scan_path >= 1 && (c->scan_path == 2 ? c->chunks_synced : c->unsynced == 0) && c->uniform_chunks && c->pending.size() <= kMaxPatch &&
-	                      !env_u64("TOKSCORE_NOINCR", 0);
+	                      !c->knob_noincr;
 	if (!eligible) return tokscore_score(c, counts, total_tokens, total_bytes);
 	hipStream_t s = c->stream;
 	uint32_t nsel = 0;
@@ -1393,8 +1401,8 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		// shard a token in up to a thousand chunks is re-scored faster.  TOKSCORE_INCR_DIV = d: the
 		// plain rule "at most 1/d of the chunks" instead (tests).
 		uint32_t limit;
-		if (getenv("TOKSCORE_INCR_DIV")) {
-			limit = c->nchunks / (uint32_t)std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3));
+		if (c->knob_incr_div) {
+			limit = c->nchunks / (uint32_t)c->knob_incr_div;
 		} else {
 			const double full_us = 50.0 + 0.95e-6 * (double)c->total; // 0.95 us per MB
 			const double fixed_us = 2 * 110.0, per_chunk_us = 2 * 0.3;
@@ -1549,7 +1557,7 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 	st = ensure_plan(c);
 	if (st) return st;
 	bool batched = c->scan_path == 2 && c->chunks_synced && c->uniform_chunks && c->simg_valid &&
-	               !env_u64("TOKSCORE_NOINCR", 0) && !env_u64("TOKSCORE_NOBATCH", 0);
+	               !c->knob_noincr && !c->knob_nobatch;
 	if (batched && c->index_state == 0) build_index(c);
 	batched = batched && c->index_state == 1;
 	if (!batched) return score_toggles_one_by_one(c, token_index, enable, K, delta_total_tokens);
@@ -1587,7 +1595,7 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		HIP_TRY(c, hipGetLastError());
 		c->stream_tokens_epoch = c->trie_epoch;
 	}
-	const uint64_t budget = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 16ull << 20));
+	const uint64_t budget = c->knob_toggle_items;
 	const StreamWork W0 = stream_work(c, false);
 	size_t first = 0;
 	while (first < moves.size()) {
