@@ -83,6 +83,17 @@ struct StreamTrieDev {      // trie.h: StreamImage
 	uint32_t nslots;
 	uint32_t root_base;
 };
+// One stream a move's string occurs in (at a token start of the vocabulary as it is), with where:
+// up to kToggleOffsets occurrence offsets from the stream's begin, in no order.  n = kToggleWhole:
+// too many (or a stream of 64 KB and more): the whole stream is walked instead.
+constexpr uint32_t kToggleOffsets = 11;
+constexpr uint16_t kToggleWhole = 0xFFFFu;
+struct ToggleItem {
+	uint32_t stream, move;
+	uint16_t n;
+	uint16_t off[kToggleOffsets];
+};
+static_assert(sizeof(ToggleItem) == 32, "two items per cache-line half");
 struct ByteCodes {
 	uint8_t code[256];     // byte -> code (StreamImage::code)
 };
@@ -104,8 +115,9 @@ struct StreamWork {
 	uint32_t streams_per_chunk;  // upper bound of the streams in one chunk
 	// batched move evaluation (launch_walk_toggles): item = move << 32 | stream; nullptr = count
 	// every stream's tokens into tg_base
-	const unsigned long long *tg_items = nullptr;
+	const ToggleItem *tg_items = nullptr;
 	uint32_t *tg_base = nullptr;        // [nstreams] tokens per stream under the vocabulary as it is
+	uint8_t *tg_starts = nullptr;       // [prep_total] written with tg_base (zeroed by the caller): 1 where a token of the vocabulary as it is starts
 	const uint32_t *tg_count = nullptr; // [kToggleLists] items appended per list (may exceed tg_cap: the surplus was not stored)
 	uint32_t tg_cap = 0;                // per list
 	const uint32_t *tg_slot = nullptr;  // [moves] the slot whose token-end bit the move flips
@@ -122,9 +134,11 @@ struct ToggleBatch {
 	const uint32_t *str_off;    // [n + 1] the move's string in `codes`
 	const uint8_t *codes;       // strings in the prepared corpus' code space
 	uint32_t *pairs;            // [pair_off[n]] scratch: the chunk of every pair
-	unsigned long long *items;  // [kToggleLists][cap_items] scratch: (move, stream) for every stream the string occurs in
+	ToggleItem *items;          // [kToggleLists][cap_items] scratch: one item for every stream the string occurs in
 	uint32_t *n_items;          // [kToggleLists] items per list, zeroed by the launcher
 	uint32_t cap_items;         // per list
+	const uint8_t *starts = nullptr; // optional (StreamWork::tg_starts): only occurrences at a token start of the
+	                            // vocabulary as it is count -- a move changes nothing in a stream without one
 	uint32_t *seen = nullptr;   // optional, one bit per stream, zeroed by the caller: a stream is listed once
 	                            // whichever moves' strings occur in it (incremental re-score)
 };
@@ -155,6 +169,11 @@ void launch_find_toggle_streams(const ToggleBatch &B, const StreamWork &W, uint3
                                 hipStream_t stream);
 void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, uint64_t max_items,
                          hipStream_t stream);
+// The items with occurrence offsets: from every occurrence the chain of the vocabulary as it is and
+// the chain with the move are walked side by side until they meet again (a few dozen bytes), the
+// difference in tokens is added to W.tg_delta[move].  launch_walk_toggles then only takes the
+// kToggleWhole items.
+void launch_local_toggles(const StreamTrieDev &T, const StreamWork &W, uint32_t num_cus, uint64_t max_items, hipStream_t stream);
 // full evaluation over the transposed ranges (W.tprep)
 bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan);
 void launch_transpose_ranges(const uint8_t *prep, uint64_t prep_readable, uint32_t range_bytes, uint32_t halo, uint32_t nblocks,

@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(1024) scan_stream_kernel(StreamTrieDev T, Stre
 		uint32_t beg = 0, end = 0;
 		if (W.tg_items) {
 			if ((item >> 6) < my_items) {
-				const uint32_t strm = (uint32_t)W.tg_items[(size_t)lane * W.tg_cap + (item >> 6)];
+				const uint32_t strm = W.tg_items[(size_t)lane * W.tg_cap + (item >> 6)].stream;
 				beg = W.pbeg[strm];
 				end = W.pbeg[strm + 1];
 			}
@@ -353,11 +353,14 @@ __global__ void __launch_bounds__(1024) list_toggle_pairs_kernel(ToggleBatch B) 
 __global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B, StreamWork W, uint32_t nchunks) {
 	__shared__ uint32_t s_bits[16][16]; // per wave: up to 512 streams of one chunk (plan_stream: at most 8 * 64)
 	__shared__ uint32_t s_cnt[16], s_at[16];
+	__shared__ uint32_t s_hits[16][64];                 // per wave and stream (the first 64 of a chunk): occurrences seen
+	__shared__ uint16_t s_off[16][64][kToggleOffsets];  // ... and where, from the stream's begin
 	const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 	const uint32_t p = blockIdx.x * 16 + wave;
 	const uint32_t npairs = B.pair_off[B.n];
 	uint32_t m = 0, s0 = 0, ns = 0;
 	if (lane < 16) s_bits[wave][lane] = 0;
+	s_hits[wave][lane] = 0;
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
 	const uint32_t chunk = p < npairs ? B.pairs[p] : 0xFFFFFFFFu;
@@ -400,13 +403,22 @@ __global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B
 					uint32_t k = 4;
 					while (k < L && W.prep[q + k] == str[k]) k++;
 					if (k < L) continue;
+					// Both chains start a stream together and take the same tokens until one starts
+					// where the string occurs: an occurrence inside a token of the vocabulary as it is
+					// cannot be where they part
+					if (B.starts && !B.starts[q]) continue;
 					uint32_t l = s0, h = s0 + ns; // last stream with pbeg <= q
 					while (h - l > 1) {
 						const uint32_t mid = (l + h) >> 1;
 						if (W.pbeg[mid] <= q) l = mid;
 						else h = mid;
 					}
-					atomicOr(&s_bits[wave][(l - s0) >> 5], 1u << ((l - s0) & 31));
+					const uint32_t si = l - s0, rel = q - W.pbeg[l];
+					atomicOr(&s_bits[wave][si >> 5], 1u << (si & 31));
+					if (si < 64) {
+						const uint32_t k = rel < 0xFFFFu ? atomicAdd(&s_hits[wave][si], 1u) : atomicAdd(&s_hits[wave][si], 1000u);
+						if (k < kToggleOffsets) s_off[wave][si][k] = (uint16_t)rel;
+					}
 				}
 			}
 		}
@@ -441,7 +453,7 @@ __global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B
 		for (uint32_t k = 0; k < 16; k++) s_at[k] += first;
 	}
 	__syncthreads();
-	unsigned long long *list = B.items + (size_t)(blockIdx.x % kToggleLists) * B.cap_items;
+	ToggleItem *list = B.items + (size_t)(blockIdx.x % kToggleLists) * B.cap_items;
 	uint32_t at = s_at[wave];
 	for (uint32_t i0 = 0; i0 < ns; i0 += 64) {
 		const uint32_t i = i0 + lane;
@@ -449,7 +461,16 @@ __global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B
 		const unsigned long long mask = __builtin_amdgcn_ballot_w64(hit);
 		if (hit) {
 			const uint32_t r = at + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-			if (r < B.cap_items) list[r] = ((unsigned long long)m << 32) | (s0 + i);
+			if (r < B.cap_items) {
+				ToggleItem it;
+				it.stream = s0 + i;
+				it.move = m;
+				const uint32_t n = i < 64 ? s_hits[wave][i] : 1000u;
+				it.n = n <= kToggleOffsets ? (uint16_t)n : kToggleWhole;
+#pragma unroll
+				for (uint32_t k = 0; k < kToggleOffsets; k++) it.off[k] = i < 64 && k < n ? s_off[wave][i][k] : (uint16_t)0;
+				list[r] = it;
+			}
 		}
 		at += (uint32_t)__builtin_popcountll(mask);
 	}
@@ -537,10 +558,11 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 					const uint32_t q = f % kToggleLists, idx = f / kToggleLists;
 					have = idx < s_count[q];
 					if (have) {
-						const unsigned long long it = W.tg_items[(size_t)q * W.tg_cap + idx];
-						strm = (uint32_t)it;
-						move = (uint32_t)(it >> 32);
-						flip_slot = W.tg_slot[move];
+						const ToggleItem *it = &W.tg_items[(size_t)q * W.tg_cap + idx];
+						have = it->n == kToggleWhole; // (the others: local_toggles_kernel)
+						strm = it->stream;
+						move = it->move;
+						if (have) flip_slot = W.tg_slot[move];
 					}
 				}
 				if (have) {
@@ -552,6 +574,7 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 					req = false;
 					if (beg < end) {
 						active = true;
+						if (!listed && W.tg_starts) W.tg_starts[beg] = 1;
 						fill = beg & ~15u;
 #pragma unroll
 						for (uint32_t k = 0; k < RING / 16; k++) {
@@ -594,6 +617,7 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 				cp = cont ? cp1 : lend;
 				if (!cont) {
 					ntok += lslot != 0 ? 1u : 0u; // (slot 0: a document separator, no token)
+					if (!listed && W.tg_starts && cp < end) W.tg_starts[cp] = 1; // the next token starts here
 					if (cp >= end) {
 						active = false;
 						req = false;
@@ -612,6 +636,96 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 			const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)acc_move, (int)leader);
 			const bool mine = acc != 0 && acc_move == m0;
 			int sum = mine ? acc : 0;
+			for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+			if (lane == leader) atomicAdd(&W.tg_delta[m0], (unsigned long long)(long long)sum);
+			pend &= ~__builtin_amdgcn_ballot_w64(mine);
+		}
+	}
+}
+
+// ---- batched move evaluation: local walks --------------------------------------------------------
+// An item with occurrence offsets.  The chain of the vocabulary as it is (A) and the chain with the
+// move's bit flipped (B) take the same tokens from the stream's begin until a token starts where the
+// string occurs; from there both are walked, whichever is behind next, until they stand on the same
+// position again -- a few dozen bytes, never past the stream's end (its cut is a token start of
+// every chain).  What lies between is counted once: occurrences are taken in ascending order and
+// those the last walk has passed are skipped.  Bytes come straight from the prepared corpus in
+// global memory (the walks are too short for a ring), the trie image from LDS.
+__device__ __forceinline__ uint32_t local_token(const LDS_AS uint8_t *l_lt, const LDS_AS uint16_t *l_base, const uint8_t *prep,
+                                                uint32_t pos, uint32_t flip_slot, uint32_t &counts) {
+	uint32_t nb = 0, d = 0, len = 1, slot = 0;
+	do {
+		const uint32_t c = prep[pos + d];
+		const uint32_t t = nb + c;
+		uint32_t x = l_lt[t] ^ c;
+		if (t == flip_slot) x ^= 0x80u;
+		if ((x & 0x7Fu) != 0) break;
+		d++;
+		if (x == 0x80u) len = d, slot = t;
+		nb = l_base[t];
+	} while (nb != 0);
+	counts += slot != 0 ? 1u : 0u; // (slot 0: a document separator, no token)
+	return pos + len;
+}
+
+__global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, StreamWork W) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char local_smem[];
+	__shared__ uint32_t s_count[kToggleLists];
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)local_smem;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
+	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
+	{
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
+		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		dst = (LDS_AS u32x4 *)(lds + label_bytes);
+		src = reinterpret_cast<const u32x4 *>(T.base);
+		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		if (threadIdx.x < kToggleLists) s_count[threadIdx.x] = min(W.tg_count[threadIdx.x], W.tg_cap);
+	}
+	__syncthreads();
+	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
+	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
+	uint32_t most = s_count[lane];
+	for (int o = 32; o > 0; o >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, o, 64));
+	const uint32_t total_lanes = gridDim.x * blockDim.x;
+	// lane q of every wave reads list q (total_lanes is a multiple of 64)
+	for (uint32_t idx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; __builtin_amdgcn_ballot_w64(idx < most) != 0; idx += total_lanes >> 6) {
+		int d = 0;
+		uint32_t move = 0;
+		if (idx < s_count[lane]) {
+			const ToggleItem it = W.tg_items[(size_t)lane * W.tg_cap + idx];
+			if (it.n != kToggleWhole && it.n != 0) {
+				move = it.move;
+				const uint32_t flip_slot = W.tg_slot[move];
+				const uint32_t beg = W.pbeg[it.stream];
+				uint32_t cur = 0; // offsets below this lie inside what has been walked
+				for (uint32_t round = 0; round < it.n; round++) {
+					uint32_t best = 0xFFFFFFFFu;
+#pragma unroll
+					for (uint32_t k = 0; k < kToggleOffsets; k++)
+						if (k < it.n && it.off[k] >= cur && it.off[k] < best) best = it.off[k];
+					if (best == 0xFFFFFFFFu) break;
+					uint32_t na = 0, nb2 = 0;
+					uint32_t pa = local_token(l_lt, l_base, W.prep, beg + best, 0xFFFFFFFFu, na);
+					uint32_t pb = local_token(l_lt, l_base, W.prep, beg + best, flip_slot, nb2);
+					while (pa != pb) {
+						if (pa < pb) pa = local_token(l_lt, l_base, W.prep, pa, 0xFFFFFFFFu, na);
+						else pb = local_token(l_lt, l_base, W.prep, pb, flip_slot, nb2);
+					}
+					d += (int)nb2 - (int)na;
+					cur = pa - beg;
+				}
+			}
+		}
+		// one atomic per move and wave (neighbouring items mostly belong to one move)
+		unsigned long long pend = __builtin_amdgcn_ballot_w64(d != 0);
+		while (pend) {
+			const uint32_t leader = (uint32_t)__builtin_ctzll(pend);
+			const uint32_t m0 = (uint32_t)__builtin_amdgcn_readlane((int)move, (int)leader);
+			const bool mine = d != 0 && move == m0;
+			int sum = mine ? d : 0;
 			for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
 			if (lane == leader) atomicAdd(&W.tg_delta[m0], (unsigned long long)(long long)sum);
 			pend &= ~__builtin_amdgcn_ballot_w64(mine);
@@ -1379,6 +1493,15 @@ void launch_find_toggle_streams(const ToggleBatch &B, const StreamWork &W, uint3
 	if (B.n == 0 || npairs == 0) return;
 	hipLaunchKernelGGL(list_toggle_pairs_kernel, dim3(B.n), dim3(1024), 0, stream, B);
 	hipLaunchKernelGGL(find_toggle_streams_kernel, dim3((npairs + 15) / 16), dim3(1024), 0, stream, B, W, nchunks);
+}
+
+void launch_local_toggles(const StreamTrieDev &T, const StreamWork &W, uint32_t num_cus, uint64_t max_items, hipStream_t stream) {
+	if (max_items == 0) return;
+	const uint32_t lds_bytes = ((T.nslots + 15) & ~15u) + ((T.nslots * 2 + 15) & ~15u);
+	const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(num_cus, (max_items + 1023) / 1024));
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&local_toggles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+	                          (int)lds_bytes);
+	hipLaunchKernelGGL(local_toggles_kernel, dim3(blocks), dim3(1024), lds_bytes, stream, T, W);
 }
 
 void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, uint64_t max_items,

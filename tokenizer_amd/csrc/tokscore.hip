@@ -144,7 +144,7 @@ struct tokscore_ctx {
 	size_t tg_meta_cap = 0;
 	uint32_t *d_tg_pairs = nullptr;
 	size_t tg_pairs_cap = 0;
-	unsigned long long *d_tg_items = nullptr;
+	ToggleItem *d_tg_items = nullptr;
 	size_t tg_items_cap = 0;
 	uint32_t *d_tg_seen = nullptr; // one bit per stream: listed already (incremental re-score)
 	size_t tg_seen_cap = 0;
@@ -153,13 +153,15 @@ struct tokscore_ctx {
 	uint8_t *d_tprep_raw = nullptr;
 	unsigned long long *d_slot_ends = nullptr; // [nslots + 2]: ends per slot | entries | positions
 	size_t slot_ends_cap = 0;
+	uint8_t *d_tok_starts = nullptr;     // [prep_total]: 1 where a token starts, same validity as d_stream_tokens
+	size_t tok_starts_cap = 0;
 	uint32_t *d_stream_tokens = nullptr; // [nstreams] tokens per stream, valid while stream_tokens_epoch == trie_epoch
 	size_t stream_tokens_cap = 0;
 	uint64_t trie_epoch = 1, stream_tokens_epoch = 0; // trie_epoch: another one whenever the device trie or the plan changes
 	// knobs of the move paths, read once at tokscore_create (not on every call)
 	bool knob_noincr = false, knob_nobatch = false;
 	uint64_t knob_incr_div = 0;      // 0: the cost estimate decides
-	uint64_t knob_toggle_items = 16ull << 20;
+	uint64_t knob_toggle_items = 4ull << 20; // items (32 B each) one batch of moves may need
 	uint64_t toggle_items = 0; // (move, stream) items walked by score_toggles so far (diagnostics)
 	// occurrence index (one bit per string and chunk), built by the first incremental re-score of a plan
 	uint32_t *d_index = nullptr;
@@ -973,7 +975,7 @@ int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool d
 	};
 	HIP_TRY(c, grow((void **)&c->d_tg_meta, &c->tg_meta_cap, blob * 2, 1));
 	HIP_TRY(c, grow((void **)&c->d_tg_pairs, &c->tg_pairs_cap, std::max<uint64_t>(1, pairs), sizeof(uint32_t)));
-	HIP_TRY(c, grow((void **)&c->d_tg_items, &c->tg_items_cap, cap_items, sizeof(unsigned long long)));
+	HIP_TRY(c, grow((void **)&c->d_tg_items, &c->tg_items_cap, cap_items, sizeof(ToggleItem)));
 	const size_t seen_words = ((size_t)c->nstreams + 31) / 32 + 1;
 	if (dedupe) {
 		HIP_TRY(c, grow((void **)&c->d_tg_seen, &c->tg_seen_cap, seen_words, sizeof(uint32_t)));
@@ -1123,7 +1125,7 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->knob_noincr = env_u64("TOKSCORE_NOINCR", 0) != 0;
 	c->knob_nobatch = env_u64("TOKSCORE_NOBATCH", 0) != 0;
 	c->knob_incr_div = getenv("TOKSCORE_INCR_DIV") ? std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)) : 0;
-	c->knob_toggle_items = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 16ull << 20));
+	c->knob_toggle_items = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 4ull << 20));
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
@@ -1168,6 +1170,7 @@ void tokscore_destroy(tokscore_ctx *c) {
 		if (c->d_tg_items) (void)hipFree(c->d_tg_items);
 		if (c->d_tg_seen) (void)hipFree(c->d_tg_seen);
 		if (c->d_stream_tokens) (void)hipFree(c->d_stream_tokens);
+		if (c->d_tok_starts) (void)hipFree(c->d_tok_starts);
 		if (c->d_slot_ends) (void)hipFree(c->d_slot_ends);
 		if (c->h_patch) (void)hipHostFree(c->h_patch);
 		for (auto &set : c->ring)
@@ -1589,8 +1592,16 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 			HIP_TRY(c, hipMalloc((void **)&c->d_stream_tokens, ((size_t)c->nstreams + 1) * sizeof(uint32_t)));
 			c->stream_tokens_cap = (size_t)c->nstreams + 1;
 		}
+		if (c->prep_total + 16 > c->tok_starts_cap) {
+			if (c->d_tok_starts) (void)hipFree(c->d_tok_starts);
+			c->d_tok_starts = nullptr, c->tok_starts_cap = 0;
+			HIP_TRY(c, hipMalloc((void **)&c->d_tok_starts, c->prep_total + 16));
+			c->tok_starts_cap = c->prep_total + 16;
+		}
+		HIP_TRY(c, hipMemsetAsync(c->d_tok_starts, 0, c->prep_total + 16, s));
 		StreamWork Wb = stream_work(c, false);
 		Wb.tg_base = c->d_stream_tokens;
+		Wb.tg_starts = c->d_tok_starts;
 		launch_walk_toggles(stream_trie_dev(c), Wb, c->splan, c->nstreams, s);
 		HIP_TRY(c, hipGetLastError());
 		c->stream_tokens_epoch = c->trie_epoch;
@@ -1607,6 +1618,7 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		ToggleUpload up;
 		st = upload_toggle_batch(c, moves.data() + first, n, false, s, &up);
 		if (st) return st;
+		up.B.starts = c->d_tok_starts;
 		StreamWork W = W0;
 		W.tg_items = up.B.items;
 		W.tg_count = up.B.n_items;
@@ -1615,7 +1627,8 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		W.tg_base = c->d_stream_tokens;
 		W.tg_delta = up.d_delta;
 		launch_find_toggle_streams(up.B, W, (uint32_t)up.pairs, c->nchunks, s);
-		launch_walk_toggles(stream_trie_dev(c), W, c->splan, up.list_cap * kToggleLists, s);
+		launch_local_toggles(stream_trie_dev(c), W, (uint32_t)c->num_cus, up.list_cap * kToggleLists, s);
+		launch_walk_toggles(stream_trie_dev(c), W, c->splan, up.list_cap * kToggleLists, s); // (the few items without a list)
 		HIP_TRY(c, hipGetLastError());
 		std::vector<uint64_t> res((size_t)n + kToggleLists / 2);
 		HIP_TRY(c, hipMemcpyAsync(res.data(), c->d_tg_meta, res.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
