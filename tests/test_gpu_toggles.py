@@ -31,10 +31,10 @@ def _check_moves(s, tokens, enabled, corpus, off, idx, en):
     return got
 
 
-@pytest.mark.parametrize("env", [{}, {"TOKSCORE_TOGGLE_ITEMS": "2000"}, {"TOKSCORE_SCAN": "tile"}])
+@pytest.mark.parametrize("env", [{}, {"TOKSCORE_TOGGLE_ITEMS": "2000", "TOKSCORE_TOGGLE_LIST": "4"}, {"TOKSCORE_SCAN": "tile"}])
 def test_deltas_equal_oracle_differences(env, monkeypatch):
-    """env: one batch / several batches (a small item budget) / the move-by-move fallback on a
-    scan path without the batched kernel."""
+    """env: one batch / several batches (a small budget of pairs) whose item lists start too short and
+    have to be provided again / the move-by-move fallback on a scan path without the batched kernel."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     corpus, off = synth.wiki_like(1_500_000, seed=31)

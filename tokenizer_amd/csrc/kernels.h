@@ -133,7 +133,7 @@ struct ToggleBatch {
 	const uint32_t *pair_off;   // [n + 1] first (move, chunk) pair of every move; pair_off[m + 1] - pair_off[m] = chunks in its row
 	const uint32_t *str_off;    // [n + 1] the move's string in `codes`
 	const uint8_t *codes;       // strings in the prepared corpus' code space
-	uint32_t *pairs;            // [pair_off[n]] scratch: the chunk of every pair
+	uint2 *pairs;               // [pair_off[n]] scratch: (chunk, move) of every pair
 	ToggleItem *items;          // [kToggleLists][cap_items] scratch: one item for every stream the string occurs in
 	uint32_t *n_items;          // [kToggleLists] items per list, zeroed by the launcher
 	uint32_t cap_items;         // per list

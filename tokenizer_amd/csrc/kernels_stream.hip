@@ -334,13 +334,13 @@ __global__ void __launch_bounds__(1024) list_toggle_pairs_kernel(ToggleBatch B) 
 		if (!w) continue;
 		uint32_t at = atomicAdd(&s_n, (uint32_t)__builtin_popcount(w));
 		while (w) {
-			if (at < cap) B.pairs[base + at] = j * 32 + (uint32_t)__builtin_ctz(w);
+			if (at < cap) B.pairs[base + at] = uint2{j * 32 + (uint32_t)__builtin_ctz(w), m};
 			w &= w - 1;
 			at++;
 		}
 	}
 	__syncthreads();
-	for (uint32_t j = s_n + threadIdx.x; j < cap; j += blockDim.x) B.pairs[base + j] = 0xFFFFFFFFu;
+	for (uint32_t j = s_n + threadIdx.x; j < cap; j += blockDim.x) B.pairs[base + j] = uint2{0xFFFFFFFFu, m};
 }
 
 // One wave per (move, chunk) pair: the chunk's bytes of the prepared corpus are searched for the
@@ -363,15 +363,10 @@ __global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B
 	s_hits[wave][lane] = 0;
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
-	const uint32_t chunk = p < npairs ? B.pairs[p] : 0xFFFFFFFFu;
+	const uint2 pair = p < npairs ? B.pairs[p] : uint2{0xFFFFFFFFu, 0u};
+	const uint32_t chunk = pair.x;
 	if (chunk < nchunks) {
-		uint32_t lo = 0, hi = B.n; // the move: last m with pair_off[m] <= p
-		while (hi - lo > 1) {
-			const uint32_t mid = (lo + hi) >> 1;
-			if (B.pair_off[mid] <= p) lo = mid;
-			else hi = mid;
-		}
-		m = lo;
+		m = pair.y;
 		s0 = W.chunk_first[chunk];
 		const uint32_t s1 = W.chunk_first[chunk + 1];
 		ns = s1 - s0 < 512 ? s1 - s0 : 512;

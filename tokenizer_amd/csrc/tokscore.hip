@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -142,10 +143,12 @@ struct tokscore_ctx {
 	// (move, chunk) pairs | the (move, stream) items
 	unsigned char *d_tg_meta = nullptr;
 	size_t tg_meta_cap = 0;
-	uint32_t *d_tg_pairs = nullptr;
+	uint2 *d_tg_pairs = nullptr;
 	size_t tg_pairs_cap = 0;
 	ToggleItem *d_tg_items = nullptr;
 	size_t tg_items_cap = 0;
+	unsigned char *h_tg_meta = nullptr; // pinned: the batch description on its way up, the results on their way down
+	size_t h_tg_meta_cap = 0;
 	uint32_t *d_tg_seen = nullptr; // one bit per stream: listed already (incremental re-score)
 	size_t tg_seen_cap = 0;
 	// row f1 on the stream image: the prepared corpus without lower-casing, transposed like d_tprep
@@ -161,7 +164,8 @@ struct tokscore_ctx {
 	// knobs of the move paths, read once at tokscore_create (not on every call)
 	bool knob_noincr = false, knob_nobatch = false;
 	uint64_t knob_incr_div = 0;      // 0: the cost estimate decides
-	uint64_t knob_toggle_items = 4ull << 20; // items (32 B each) one batch of moves may need
+	uint64_t knob_toggle_items = 32ull << 20; // (move, chunk) pairs one batch of moves may have
+	uint64_t tg_list_hint = 8192;             // entries per item list provided first (doubled when a batch needed more)
 	uint64_t toggle_items = 0; // (move, stream) items walked by score_toggles so far (diagnostics)
 	// occurrence index (one bit per string and chunk), built by the first incremental re-score of a plan
 	uint32_t *d_index = nullptr;
@@ -934,7 +938,10 @@ struct ToggleUpload {
 	const uint32_t *d_slots = nullptr;
 	unsigned long long *d_delta = nullptr;
 };
-int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool dedupe, hipStream_t s, ToggleUpload *up) {
+// list_cap_hint: entries per item list to provide when fewer than the worst case are expected (0: the
+// worst case, which cannot overflow; otherwise the caller checks the counts and comes again)
+int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool dedupe, hipStream_t s, ToggleUpload *up,
+                        uint64_t list_cap_hint = 0) {
 	const uint64_t per_chunk = c->widest_chunk; // no chunk has more streams (plan_stream)
 	uint64_t pairs = 0;
 	for (uint32_t k = 0; k < n; k++) pairs += m[k].chunks;
@@ -942,7 +949,8 @@ int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool d
 	// items: kToggleLists lists; list q takes what the workgroups q, q + kToggleLists, .. of the search find
 	// (16 pairs per workgroup), so this many entries per list always suffice
 	const uint64_t find_blocks = (pairs + 15) / 16;
-	const uint64_t list_cap = std::max<uint64_t>(1, (find_blocks + kToggleLists - 1) / kToggleLists * 16 * per_chunk);
+	uint64_t list_cap = std::max<uint64_t>(1, (find_blocks + kToggleLists - 1) / kToggleLists * 16 * per_chunk);
+	if (list_cap_hint) list_cap = std::min(list_cap, list_cap_hint);
 	const uint64_t cap_items = list_cap * kToggleLists;
 	std::vector<uint32_t> meta((size_t)2 * n + kToggleLists, 0);
 	std::vector<uint8_t> codes;
@@ -974,16 +982,23 @@ int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool d
 		return e;
 	};
 	HIP_TRY(c, grow((void **)&c->d_tg_meta, &c->tg_meta_cap, blob * 2, 1));
-	HIP_TRY(c, grow((void **)&c->d_tg_pairs, &c->tg_pairs_cap, std::max<uint64_t>(1, pairs), sizeof(uint32_t)));
+	HIP_TRY(c, grow((void **)&c->d_tg_pairs, &c->tg_pairs_cap, std::max<uint64_t>(1, pairs), sizeof(uint2)));
 	HIP_TRY(c, grow((void **)&c->d_tg_items, &c->tg_items_cap, cap_items, sizeof(ToggleItem)));
 	const size_t seen_words = ((size_t)c->nstreams + 31) / 32 + 1;
 	if (dedupe) {
 		HIP_TRY(c, grow((void **)&c->d_tg_seen, &c->tg_seen_cap, seen_words, sizeof(uint32_t)));
 		HIP_TRY(c, hipMemsetAsync(c->d_tg_seen, 0, seen_words * sizeof(uint32_t), s));
 	}
-	// (pageable source: the copy has left the host buffer when the call returns)
-	HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta, meta.data(), codes_at, hipMemcpyHostToDevice, s));
-	if (!codes.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta + codes_at, codes.data(), codes.size(), hipMemcpyHostToDevice, s));
+	// one copy from a pinned buffer (every caller waits for the stream before the next batch is built)
+	if (blob > c->h_tg_meta_cap) {
+		if (c->h_tg_meta) (void)hipHostFree(c->h_tg_meta);
+		c->h_tg_meta = nullptr, c->h_tg_meta_cap = 0;
+		HIP_TRY(c, hipHostMalloc((void **)&c->h_tg_meta, blob * 2, hipHostMallocDefault));
+		c->h_tg_meta_cap = blob * 2;
+	}
+	memcpy(c->h_tg_meta, meta.data(), codes_at);
+	if (!codes.empty()) memcpy(c->h_tg_meta + codes_at, codes.data(), codes.size());
+	HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta, c->h_tg_meta, codes_at + codes.size(), hipMemcpyHostToDevice, s));
 	uint32_t *words = (uint32_t *)c->d_tg_meta;
 	ToggleBatch &B = up->B;
 	B.n = n;
@@ -1125,7 +1140,8 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->knob_noincr = env_u64("TOKSCORE_NOINCR", 0) != 0;
 	c->knob_nobatch = env_u64("TOKSCORE_NOBATCH", 0) != 0;
 	c->knob_incr_div = getenv("TOKSCORE_INCR_DIV") ? std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)) : 0;
-	c->knob_toggle_items = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 4ull << 20));
+	c->knob_toggle_items = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 32ull << 20));
+	c->tg_list_hint = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_LIST", 8192));
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
@@ -1169,6 +1185,7 @@ void tokscore_destroy(tokscore_ctx *c) {
 		if (c->d_tg_pairs) (void)hipFree(c->d_tg_pairs);
 		if (c->d_tg_items) (void)hipFree(c->d_tg_items);
 		if (c->d_tg_seen) (void)hipFree(c->d_tg_seen);
+		if (c->h_tg_meta) (void)hipHostFree(c->h_tg_meta);
 		if (c->d_stream_tokens) (void)hipFree(c->d_stream_tokens);
 		if (c->d_tok_starts) (void)hipFree(c->d_tok_starts);
 		if (c->d_slot_ends) (void)hipFree(c->d_slot_ends);
@@ -1571,6 +1588,9 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		st = tokscore_score_incremental(c, counts.data(), nullptr, nullptr);
 		if (st) return st;
 	}
+	const bool trace = getenv("TOKSCORE_TRACE_HOST") != nullptr;
+	auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t_begin = now();
 	std::vector<ToggleSpec> moves;
 	std::vector<uint64_t> move_k;
 	for (uint64_t k = 0; k < K; k++) {
@@ -1583,6 +1603,7 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		move_k.push_back(k);
 	}
 	if (moves.empty()) return TOKSCORE_OK;
+	const double t_peek = now();
 	// tokens per stream under the vocabulary as it is: one walk over all streams, kept until the
 	// device trie changes
 	if (c->stream_tokens_epoch != c->trie_epoch) {
@@ -1613,11 +1634,13 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		// a batch: as many moves as the item budget holds (one at least)
 		size_t last = first;
 		uint64_t pairs = 0;
-		while (last < moves.size() && (last == first || (pairs + moves[last].chunks) * c->widest_chunk <= budget)) pairs += moves[last++].chunks;
+		while (last < moves.size() && (last == first || pairs + moves[last].chunks <= budget)) pairs += moves[last++].chunks;
 		const uint32_t n = (uint32_t)(last - first);
 		ToggleUpload up;
-		st = upload_toggle_batch(c, moves.data() + first, n, false, s, &up);
+		const double t_up0 = now();
+		st = upload_toggle_batch(c, moves.data() + first, n, false, s, &up, c->tg_list_hint);
 		if (st) return st;
+		const double t_up1 = now();
 		up.B.starts = c->d_tok_starts;
 		StreamWork W = W0;
 		W.tg_items = up.B.items;
@@ -1630,14 +1653,22 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		launch_local_toggles(stream_trie_dev(c), W, (uint32_t)c->num_cus, up.list_cap * kToggleLists, s);
 		launch_walk_toggles(stream_trie_dev(c), W, c->splan, up.list_cap * kToggleLists, s); // (the few items without a list)
 		HIP_TRY(c, hipGetLastError());
-		std::vector<uint64_t> res((size_t)n + kToggleLists / 2);
-		HIP_TRY(c, hipMemcpyAsync(res.data(), c->d_tg_meta, res.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+		// (results come back into the pinned buffer the description left from: the upload is done by then)
+		const uint64_t *res = reinterpret_cast<const uint64_t *>(c->h_tg_meta);
+		HIP_TRY(c, hipMemcpyAsync(c->h_tg_meta, c->d_tg_meta, ((size_t)n + kToggleLists / 2) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+		const double t_l = now();
 		HIP_TRY(c, hipStreamSynchronize(s));
-		const uint32_t *per_list = reinterpret_cast<const uint32_t *>(res.data() + n);
-		for (uint32_t q = 0; q < kToggleLists; q++) {
-			if (per_list[q] > up.B.cap_items) return fail(c, TOKSCORE_E_INTERNAL, "score_toggles: more streams than the chunks can hold");
-			c->toggle_items += per_list[q];
+		if (trace) fprintf(stderr, "score_toggles: peek %.0f us, base %.0f, upload %.0f, launches %.0f, wait %.0f\n", t_peek - t_begin, t_up0 - t_peek, t_up1 - t_up0, t_l - t_up1, now() - t_l);
+		const uint32_t *per_list = reinterpret_cast<const uint32_t *>(res + n);
+		uint32_t most = 0;
+		for (uint32_t q = 0; q < kToggleLists; q++) most = std::max(most, per_list[q]);
+		if (most > up.B.cap_items) {
+			// the lists were too short for this batch (what did not fit was counted, not stored):
+			// the same batch again with room for it
+			c->tg_list_hint = 2ull * most;
+			continue;
 		}
+		for (uint32_t q = 0; q < kToggleLists; q++) c->toggle_items += per_list[q];
 		for (uint32_t m = 0; m < n; m++) delta_total_tokens[move_k[first + m]] = (int64_t)res[m];
 		first = last;
 	}
