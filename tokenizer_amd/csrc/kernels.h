@@ -133,7 +133,10 @@ struct ToggleBatch {
 	const uint32_t *pair_off;   // [n + 1] first (move, chunk) pair of every move; pair_off[m + 1] - pair_off[m] = chunks in its row
 	const uint32_t *str_off;    // [n + 1] the move's string in `codes`
 	const uint8_t *codes;       // strings in the prepared corpus' code space
-	uint2 *pairs;               // [pair_off[n]] scratch: (chunk, move) of every pair
+	uint4 *pairs;               // [pair_off[n]] scratch, one record per pair: first stream | streams (10 bits) + move << 10 |
+	                            // prepared offsets of the chunk's begin and end (streams = 0: nothing there)
+	const uint4 *moves;         // [n] per move: str_off | bytes | its first four codes as a dword | their mask
+	const uint32_t *chunk_first, *pbeg; // StreamWork's, for the kernel that writes `pairs`
 	ToggleItem *items;          // [kToggleLists][cap_items] scratch: one item for every stream the string occurs in
 	uint32_t *n_items;          // [kToggleLists] items per list, zeroed by the launcher
 	uint32_t cap_items;         // per list

@@ -334,13 +334,25 @@ __global__ void __launch_bounds__(1024) list_toggle_pairs_kernel(ToggleBatch B) 
 		if (!w) continue;
 		uint32_t at = atomicAdd(&s_n, (uint32_t)__builtin_popcount(w));
 		while (w) {
-			if (at < cap) B.pairs[base + at] = uint2{j * 32 + (uint32_t)__builtin_ctz(w), m};
+			if (at < cap) B.pairs[base + at] = uint4{j * 32 + (uint32_t)__builtin_ctz(w), m << 10, 1u, 0u}; // (fill_toggle_pairs_kernel completes it)
 			w &= w - 1;
 			at++;
 		}
 	}
 	__syncthreads();
-	for (uint32_t j = s_n + threadIdx.x; j < cap; j += blockDim.x) B.pairs[base + j] = uint2{0xFFFFFFFFu, m};
+	for (uint32_t j = s_n + threadIdx.x; j < cap; j += blockDim.x) B.pairs[base + j] = uint4{0u, m << 10, 0u, 0u};
+}
+
+// A pair's record as the search wants it (ToggleBatch::pairs): looked up here, one thread per pair,
+// where the latency of the four dependent loads is hidden, not in front of every search wave.
+__global__ void __launch_bounds__(256) fill_toggle_pairs_kernel(ToggleBatch B, uint32_t npairs) {
+	const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+	if (p >= npairs) return;
+	const uint4 r = B.pairs[p];
+	if (r.z == 0) return; // nothing there
+	const uint32_t s0 = B.chunk_first[r.x], s1 = B.chunk_first[r.x + 1];
+	const uint32_t ns = s1 - s0 < 512 ? s1 - s0 : 512; // (plan_stream: at most 8 * 64 streams in a chunk)
+	B.pairs[p] = uint4{s0, ns | r.y, B.pbeg[s0], B.pbeg[s1]};
 }
 
 // One wave per (move, chunk) pair: the chunk's bytes of the prepared corpus are searched for the
@@ -363,22 +375,18 @@ __global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B
 	s_hits[wave][lane] = 0;
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 	__builtin_amdgcn_wave_barrier();
-	const uint2 pair = p < npairs ? B.pairs[p] : uint2{0xFFFFFFFFu, 0u};
-	const uint32_t chunk = pair.x;
-	if (chunk < nchunks) {
-		m = pair.y;
-		s0 = W.chunk_first[chunk];
-		const uint32_t s1 = W.chunk_first[chunk + 1];
-		ns = s1 - s0 < 512 ? s1 - s0 : 512;
-		const uint32_t a = W.pbeg[s0], b = W.pbeg[s1];
-		const uint32_t L = B.str_off[m + 1] - B.str_off[m];
-		const uint8_t *str = B.codes + B.str_off[m];
+	const uint4 pair = p < npairs ? B.pairs[p] : uint4{0u, 0u, 0u, 0u};
+	ns = pair.y & 1023u;
+	if (ns != 0) {
+		m = pair.y >> 10;
+		s0 = pair.x;
+		const uint32_t a = pair.z, b = pair.w;
+		const uint4 mv = B.moves[m];
+		const uint32_t L = mv.y, pat = mv.z, msk = mv.w;
+		const uint8_t *str = B.codes + mv.x;
 		if (L >= 2 && b - a >= L) { // (a one-byte string cannot be toggled as a token end: the root row is all token ends)
 			// 16 positions per lane and step, the string's first four bytes compared as one dword at
 			// every byte alignment; what matches there is compared on from memory
-			uint32_t pat = 0;
-			for (uint32_t k = 0; k < 4 && k < L; k++) pat |= (uint32_t)str[k] << (8 * k);
-			const uint32_t msk = L >= 4 ? 0xFFFFFFFFu : (1u << (8 * L)) - 1u;
 			for (uint32_t base = (a & ~15u) + lane * 16; base < b; base += 64 * 16) {
 				const u32x4 v = *reinterpret_cast<const u32x4 *>(W.prep + base);
 				const uint32_t w[5] = {v[0], v[1], v[2], v[3], *reinterpret_cast<const uint32_t *>(W.prep + base + 16)};
@@ -1486,8 +1494,12 @@ void launch_find_toggle_streams(const ToggleBatch &B, const StreamWork &W, uint3
                                 hipStream_t stream) {
 	(void)hipMemsetAsync(B.n_items, 0, kToggleLists * sizeof(uint32_t), stream);
 	if (B.n == 0 || npairs == 0) return;
-	hipLaunchKernelGGL(list_toggle_pairs_kernel, dim3(B.n), dim3(1024), 0, stream, B);
-	hipLaunchKernelGGL(find_toggle_streams_kernel, dim3((npairs + 15) / 16), dim3(1024), 0, stream, B, W, nchunks);
+	ToggleBatch Bw = B;
+	Bw.chunk_first = W.chunk_first;
+	Bw.pbeg = W.pbeg;
+	hipLaunchKernelGGL(list_toggle_pairs_kernel, dim3(B.n), dim3(1024), 0, stream, Bw);
+	hipLaunchKernelGGL(fill_toggle_pairs_kernel, dim3((npairs + 255) / 256), dim3(256), 0, stream, Bw, npairs);
+	hipLaunchKernelGGL(find_toggle_streams_kernel, dim3((npairs + 15) / 16), dim3(1024), 0, stream, Bw, W, nchunks);
 }
 
 void launch_local_toggles(const StreamTrieDev &T, const StreamWork &W, uint32_t num_cus, uint64_t max_items, hipStream_t stream) {

@@ -143,7 +143,7 @@ struct tokscore_ctx {
 	// (move, chunk) pairs | the (move, stream) items
 	unsigned char *d_tg_meta = nullptr;
 	size_t tg_meta_cap = 0;
-	uint2 *d_tg_pairs = nullptr;
+	uint4 *d_tg_pairs = nullptr;
 	size_t tg_pairs_cap = 0;
 	ToggleItem *d_tg_items = nullptr;
 	size_t tg_items_cap = 0;
@@ -971,6 +971,17 @@ int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool d
 		for (uint64_t i = c->h_vocab_off[m[k].token]; i < c->h_vocab_off[m[k].token + 1]; i++) codes.push_back(c->simg.code[c->h_vocab_bytes[i]]);
 	}
 	meta.push_back((uint32_t)codes.size());
+	while (meta.size() % 4) meta.push_back(0); // the move table is read as 16-byte records
+	const size_t moves_at = meta.size();
+	for (uint32_t k = 0; k < n; k++) {
+		const uint32_t at = meta[soff_at + k], len = meta[soff_at + k + 1] - at;
+		uint32_t pat = 0;
+		for (uint32_t i = 0; i < 4 && i < len; i++) pat |= (uint32_t)codes[at + i] << (8 * i);
+		meta.push_back(at);
+		meta.push_back(len);
+		meta.push_back(pat);
+		meta.push_back(len >= 4 ? 0xFFFFFFFFu : (1u << (8 * len)) - 1u);
+	}
 	const size_t codes_at = meta.size() * sizeof(uint32_t);
 	const size_t blob = codes_at + ((codes.size() + 15) & ~(size_t)15) + 16;
 	auto grow = [&](void **p, size_t *cap, size_t need, size_t elem) -> hipError_t {
@@ -982,7 +993,7 @@ int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool d
 		return e;
 	};
 	HIP_TRY(c, grow((void **)&c->d_tg_meta, &c->tg_meta_cap, blob * 2, 1));
-	HIP_TRY(c, grow((void **)&c->d_tg_pairs, &c->tg_pairs_cap, std::max<uint64_t>(1, pairs), sizeof(uint2)));
+	HIP_TRY(c, grow((void **)&c->d_tg_pairs, &c->tg_pairs_cap, std::max<uint64_t>(1, pairs), sizeof(uint4)));
 	HIP_TRY(c, grow((void **)&c->d_tg_items, &c->tg_items_cap, cap_items, sizeof(ToggleItem)));
 	const size_t seen_words = ((size_t)c->nstreams + 31) / 32 + 1;
 	if (dedupe) {
@@ -1007,6 +1018,8 @@ int upload_toggle_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, bool d
 	B.rows = words + rows_at;
 	B.pair_off = words + poff_at;
 	B.str_off = words + soff_at;
+	B.moves = reinterpret_cast<const uint4 *>(words + moves_at);
+	B.chunk_first = nullptr, B.pbeg = nullptr; // (the launcher fills them in from its StreamWork)
 	B.codes = c->d_tg_meta + codes_at;
 	B.pairs = c->d_tg_pairs;
 	B.items = c->d_tg_items;
