@@ -117,7 +117,8 @@ struct StreamWork {
 	// every stream's tokens into tg_base
 	const ToggleItem *tg_items = nullptr;
 	uint32_t *tg_base = nullptr;        // [nstreams] tokens per stream under the vocabulary as it is
-	uint8_t *tg_starts = nullptr;       // [prep_total] written with tg_base (zeroed by the caller): 1 where a token of the vocabulary as it is starts
+	const uint32_t *tg_order = nullptr; // [nstreams] with tg_base: the streams by length, longest first (optional)
+	unsigned long long *tg_starts = nullptr; // [prep_total / 64 + 1] written with tg_base (zeroed by the caller): bit q = a token of the vocabulary as it is starts at q
 	const uint32_t *tg_count = nullptr; // [kToggleLists] items appended per list (may exceed tg_cap: the surplus was not stored)
 	uint32_t tg_cap = 0;                // per list
 	const uint32_t *tg_slot = nullptr;  // [moves] the slot whose token-end bit the move flips
@@ -140,7 +141,7 @@ struct ToggleBatch {
 	ToggleItem *items;          // [kToggleLists][cap_items] scratch: one item for every stream the string occurs in
 	uint32_t *n_items;          // [kToggleLists] items per list, zeroed by the launcher
 	uint32_t cap_items;         // per list
-	const uint8_t *starts = nullptr; // optional (StreamWork::tg_starts): only occurrences at a token start of the
+	const unsigned long long *starts = nullptr; // optional (StreamWork::tg_starts): only occurrences at a token start of the
 	                            // vocabulary as it is count -- a move changes nothing in a stream without one
 	uint32_t *seen = nullptr;   // optional, one bit per stream, zeroed by the caller: a stream is listed once
 	                            // whichever moves' strings occur in it (incremental re-score)
@@ -172,6 +173,8 @@ void launch_find_toggle_streams(const ToggleBatch &B, const StreamWork &W, uint3
                                 hipStream_t stream);
 void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, uint64_t max_items,
                          hipStream_t stream);
+// W.tg_base / W.tg_starts for all streams (the vocabulary as it is), W.tg_order optional
+void launch_count_streams(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, hipStream_t stream);
 // The items with occurrence offsets: from every occurrence the chain of the vocabulary as it is and
 // the chain with the move are walked side by side until they meet again (a few dozen bytes), the
 // difference in tokens is added to W.tg_delta[move].  launch_walk_toggles then only takes the

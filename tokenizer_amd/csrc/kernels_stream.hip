@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B
 					// Both chains start a stream together and take the same tokens until one starts
 					// where the string occurs: an occurrence inside a token of the vocabulary as it is
 					// cannot be where they part
-					if (B.starts && !B.starts[q]) continue;
+					if (B.starts && !((B.starts[q >> 6] >> (q & 63)) & 1ull)) continue;
 					uint32_t l = s0, h = s0 + ns; // last stream with pbeg <= q
 					while (h - l > 1) {
 						const uint32_t mid = (l + h) >> 1;
@@ -526,7 +526,16 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 	const uint32_t share = ((total + total_waves - 1) / total_waves + 63) & ~63u;
 	const uint64_t lo64 = (uint64_t)(blockIdx.x * waves + wave) * share;
 	uint32_t next = uni32(lo64 < total ? (uint32_t)lo64 : total);
-	const uint32_t stop = uni32(lo64 + share < total ? (uint32_t)(lo64 + share) : total);
+	uint32_t stop = uni32(lo64 + share < total ? (uint32_t)(lo64 + share) : total);
+	// All streams, longest first (W.tg_order): wave w takes entries w, w + waves, w + 2 waves, .. of
+	// that order -- every wave a like mix, and the long streams are under way when the short ones
+	// fill the gaps, instead of one 2 KB stream deciding when the launch ends.
+	const bool ordered = !listed && W.tg_order != nullptr;
+	const uint32_t wave_global = blockIdx.x * waves + wave;
+	if (ordered) {
+		next = 0;
+		stop = uni32((total + total_waves - 1) / total_waves);
+	}
 
 	bool active = false, req = false;
 	uint32_t beg = 0, end = 0, cp = 0, lend = 0, lslot = 0, nb = 0, fill = 0, ntok = 0;
@@ -557,6 +566,11 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 			if (!active && f < stop) {
 				bool have = true;
 				strm = f;
+				if (ordered) {
+					const uint64_t at = (uint64_t)f * total_waves + wave_global;
+					have = at < total;
+					strm = have ? W.tg_order[at] : 0u;
+				}
 				if (listed) {
 					const uint32_t q = f % kToggleLists, idx = f / kToggleLists;
 					have = idx < s_count[q];
@@ -577,7 +591,6 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 					req = false;
 					if (beg < end) {
 						active = true;
-						if (!listed && W.tg_starts) W.tg_starts[beg] = 1;
 						fill = beg & ~15u;
 #pragma unroll
 						for (uint32_t k = 0; k < RING / 16; k++) {
@@ -620,7 +633,6 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 				cp = cont ? cp1 : lend;
 				if (!cont) {
 					ntok += lslot != 0 ? 1u : 0u; // (slot 0: a document separator, no token)
-					if (!listed && W.tg_starts && cp < end) W.tg_starts[cp] = 1; // the next token starts here
 					if (cp >= end) {
 						active = false;
 						req = false;
@@ -642,6 +654,136 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 			for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
 			if (lane == leader) atomicAdd(&W.tg_delta[m0], (unsigned long long)(long long)sum);
 			pend &= ~__builtin_amdgcn_ballot_w64(mine);
+		}
+	}
+}
+
+// ---- batched move evaluation: the vocabulary as it is ---------------------------------------------
+// Tokens per stream (W.tg_base) and where tokens start (W.tg_starts, one bit per byte, zeroed by the caller) under
+// the trie as it stands: every stream walked once.  Streams are a few hundred bytes, so what a
+// lane spends per stream outside the walk decides: a lane takes the streams L, L + lanes, L + 2
+// lanes, .. of the longest-first order (W.tg_order: every lane a like mix) and has the next one's
+// cuts and first bytes in registers before the current one ends -- its number, its cuts and its
+// bytes are three dependent loads, issued one per round of lookups, each used a round later.
+template <uint32_t RING>
+__global__ void __launch_bounds__(1024) count_streams_kernel(StreamTrieDev T, StreamWork W) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char count_streams_smem[];
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)count_streams_smem;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = uni32(threadIdx.x >> 6);
+	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
+	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
+	{
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
+		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		dst = (LDS_AS u32x4 *)(lds + label_bytes);
+		src = reinterpret_cast<const u32x4 *>(T.base);
+		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+	}
+	__syncthreads();
+	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
+	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
+	LDS_AS unsigned char *ring = lds + label_bytes + info_bytes + (wave * 64 + lane) * RING;
+	const uint32_t total = W.nstreams;
+	const uint32_t lanes = gridDim.x * blockDim.x;
+	uint64_t at = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; // position in the order of this lane's next stream
+
+	bool active = false, req = false;
+	uint32_t strm = 0, end = 0, cp = 0, lend = 0, lslot = 0, nb = 0, fill = 0, ntok = 0;
+	uint32_t stage = 0, n_strm = 0, n_beg = 0, n_end = 0; // the stream after this one: 0 nothing yet, 1 number, 2 cuts, 3 bytes asked for
+	u32x4 n_pre[RING / 16];
+	u32x4 data = {0, 0, 0, 0};
+	// token starts: one bit per prepared byte, collected per 64-byte window in a register and OR-ed
+	// into the map when the walk leaves the window (a byte store per token was what the kernel
+	// waited for: 26 M scattered partial-line writes)
+	unsigned long long wmask = 0;
+	uint32_t wword = 0;
+	auto mark = [&](uint32_t q) {
+		const uint32_t w = q >> 6;
+		if (w != wword) {
+			if (wmask) atomicOr(&W.tg_starts[wword], wmask);
+			wword = w, wmask = 0;
+		}
+		wmask |= 1ull << (q & 63);
+	};
+	for (;;) {
+		// ---- one step of the next stream's preparation; its loads are used a round from now ----
+		if (stage == 2) {
+			if (n_beg < n_end) {
+#pragma unroll
+				for (uint32_t k = 0; k < RING / 16; k++) n_pre[k] = *reinterpret_cast<const u32x4 *>(W.prep + (n_beg & ~15u) + 16 * k);
+			}
+			stage = 3;
+		} else if (stage == 1) {
+			n_beg = W.pbeg[n_strm];
+			n_end = W.pbeg[n_strm + 1];
+			stage = 2;
+		} else if (stage == 0 && at < total) {
+			n_strm = W.tg_order ? W.tg_order[at] : (uint32_t)at;
+			at += lanes;
+			stage = 1;
+		}
+		if (!active && stage == 3) {
+			strm = n_strm;
+			end = n_end;
+			cp = lend = n_beg;
+			lslot = 0, nb = 0, ntok = 0;
+			req = false;
+			stage = 0;
+			if (n_beg < n_end) {
+				active = true;
+				if (W.tg_starts) mark(n_beg);
+				fill = n_beg & ~15u;
+#pragma unroll
+				for (uint32_t k = 0; k < RING / 16; k++) {
+					*(LDS_AS u32x4 *)(ring + (fill & (RING - 1))) = n_pre[k];
+					fill += 16;
+				}
+			} else {
+				W.tg_base[strm] = 0; // an empty stream (a dropped cut)
+			}
+		}
+		wave_sync();
+		if (__builtin_amdgcn_ballot_w64(active) == 0) {
+			if (__builtin_amdgcn_ballot_w64(stage != 0 || at < total) == 0) break;
+			continue;
+		}
+		// ---- ring refill and a round of lookups, as in scan_stream_kernel ----
+		if (req) {
+			*(LDS_AS u32x4 *)(ring + (fill & (RING - 1))) = data;
+			fill += 16;
+		}
+		req = active && (fill - lend) <= RING - 16;
+		if (req) data = *reinterpret_cast<const u32x4 *>(W.prep + fill);
+		wave_sync();
+		for (uint32_t it = 0; it < kRound; it++) {
+			if (active) {
+				const uint32_t c = ring[cp & (RING - 1)];
+				const uint32_t t = nb + c;
+				const uint32_t x = l_lt[t] ^ c; // 0x80: hit on a token end, 0: hit, else miss
+				const uint32_t b = l_base[t];
+				const uint32_t cp1 = cp + 1;
+				const bool term = x == 0x80u;
+				lend = term ? cp1 : lend;
+				lslot = term ? t : lslot;
+				nb = (x & 0x7Fu) == 0 ? b : 0u;
+				const bool cont = nb != 0;
+				cp = cont ? cp1 : lend;
+				if (!cont) {
+					ntok += lslot != 0 ? 1u : 0u; // (slot 0: a document separator, no token)
+					if (cp < end) {
+						if (W.tg_starts) mark(cp); // the next token starts here
+					} else {
+						active = false;
+						req = false;
+						W.tg_base[strm] = ntok;
+						if (wmask) atomicOr(&W.tg_starts[wword], wmask);
+						wmask = 0;
+					}
+				}
+			}
+			if (__builtin_amdgcn_ballot_w64(active) == 0) break;
 		}
 	}
 }
@@ -1500,6 +1642,22 @@ void launch_find_toggle_streams(const ToggleBatch &B, const StreamWork &W, uint3
 	hipLaunchKernelGGL(list_toggle_pairs_kernel, dim3(B.n), dim3(1024), 0, stream, Bw);
 	hipLaunchKernelGGL(fill_toggle_pairs_kernel, dim3((npairs + 255) / 256), dim3(256), 0, stream, Bw, npairs);
 	hipLaunchKernelGGL(find_toggle_streams_kernel, dim3((npairs + 15) / 16), dim3(1024), 0, stream, Bw, W, nchunks);
+}
+
+void launch_count_streams(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, hipStream_t stream) {
+	if (W.nstreams == 0) return;
+	const uint32_t image = ((T.nslots + 15) & ~15u) + ((T.nslots * 2 + 15) & ~15u);
+	const uint32_t lds_total = 160 * 1024 - 1024;
+	const uint32_t waves = std::max<uint32_t>(1, std::min<uint32_t>(16, (lds_total - image) / (64 * plan.ring)));
+	const uint32_t lds_bytes = image + waves * 64 * plan.ring;
+	const uint64_t lanes_per_block = 64ull * waves;
+	const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(plan.blocks, (W.nstreams + lanes_per_block - 1) / lanes_per_block));
+	auto go = [&](auto kernel) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+		hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64 * waves), lds_bytes, stream, T, W);
+	};
+	if (plan.ring == 64) go(&count_streams_kernel<64>);
+	else go(&count_streams_kernel<128>);
 }
 
 void launch_local_toggles(const StreamTrieDev &T, const StreamWork &W, uint32_t num_cus, uint64_t max_items, hipStream_t stream) {

@@ -156,7 +156,8 @@ struct tokscore_ctx {
 	uint8_t *d_tprep_raw = nullptr;
 	unsigned long long *d_slot_ends = nullptr; // [nslots + 2]: ends per slot | entries | positions
 	size_t slot_ends_cap = 0;
-	uint8_t *d_tok_starts = nullptr;     // [prep_total]: 1 where a token starts, same validity as d_stream_tokens
+	uint32_t *d_stream_order = nullptr;  // [nstreams] streams by length, longest first (plan_stream)
+	unsigned long long *d_tok_starts = nullptr; // one bit per prepared byte: a token starts there; same validity as d_stream_tokens
 	size_t tok_starts_cap = 0;
 	uint32_t *d_stream_tokens = nullptr; // [nstreams] tokens per stream, valid while stream_tokens_epoch == trie_epoch
 	size_t stream_tokens_cap = 0;
@@ -312,6 +313,8 @@ void free_plan(tokscore_ctx *c) {
 	if (c->d_slab) (void)hipFree(c->d_slab);
 	if (c->d_pbeg) (void)hipFree(c->d_pbeg);
 	c->d_pbeg = nullptr;
+	if (c->d_stream_order) (void)hipFree(c->d_stream_order);
+	c->d_stream_order = nullptr;
 	if (c->d_chunk_first) (void)hipFree(c->d_chunk_first);
 	c->d_chunk_first = nullptr;
 	if (c->d_range_state) (void)hipFree(c->d_range_state);
@@ -637,6 +640,14 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_pbeg, (ns + 1) * sizeof(uint32_t)));
 	HIP_TRY(c, hipMemcpy(c->d_pbeg, pb.data(), (ns + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
+	{
+		// the streams longest first, for the walk over all of them (tokscore_score_toggles)
+		std::vector<uint32_t> order(ns);
+		for (size_t j = 0; j < ns; j++) order[j] = (uint32_t)j;
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return pb[x + 1] - pb[x] > pb[y + 1] - pb[y]; });
+		HIP_TRY(c, hipMalloc((void **)&c->d_stream_order, std::max<size_t>(1, ns) * sizeof(uint32_t)));
+		HIP_TRY(c, hipMemcpy(c->d_stream_order, order.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice));
+	}
 	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_begin, c->h_chunk_begin.size() * sizeof(uint64_t)));
 	HIP_TRY(c, hipMemcpy(c->d_chunk_begin, c->h_chunk_begin.data(), c->h_chunk_begin.size() * sizeof(uint64_t),
 	                     hipMemcpyHostToDevice));
@@ -1626,17 +1637,19 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 			HIP_TRY(c, hipMalloc((void **)&c->d_stream_tokens, ((size_t)c->nstreams + 1) * sizeof(uint32_t)));
 			c->stream_tokens_cap = (size_t)c->nstreams + 1;
 		}
-		if (c->prep_total + 16 > c->tok_starts_cap) {
+		const size_t start_words = (size_t)(c->prep_total / 64 + 2);
+		if (start_words > c->tok_starts_cap) {
 			if (c->d_tok_starts) (void)hipFree(c->d_tok_starts);
 			c->d_tok_starts = nullptr, c->tok_starts_cap = 0;
-			HIP_TRY(c, hipMalloc((void **)&c->d_tok_starts, c->prep_total + 16));
-			c->tok_starts_cap = c->prep_total + 16;
+			HIP_TRY(c, hipMalloc((void **)&c->d_tok_starts, start_words * sizeof(unsigned long long)));
+			c->tok_starts_cap = start_words;
 		}
-		HIP_TRY(c, hipMemsetAsync(c->d_tok_starts, 0, c->prep_total + 16, s));
+		HIP_TRY(c, hipMemsetAsync(c->d_tok_starts, 0, start_words * sizeof(unsigned long long), s));
 		StreamWork Wb = stream_work(c, false);
 		Wb.tg_base = c->d_stream_tokens;
 		Wb.tg_starts = c->d_tok_starts;
-		launch_walk_toggles(stream_trie_dev(c), Wb, c->splan, c->nstreams, s);
+		Wb.tg_order = c->d_stream_order;
+		launch_count_streams(stream_trie_dev(c), Wb, c->splan, s);
 		HIP_TRY(c, hipGetLastError());
 		c->stream_tokens_epoch = c->trie_epoch;
 	}
