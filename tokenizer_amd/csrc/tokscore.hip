@@ -642,6 +642,14 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 	HIP_TRY(c, hipMemcpy(c->d_pbeg, pb.data(), (ns + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
 	{
 		// the streams longest first, for the walk over all of them (tokscore_score_toggles)
+		if (getenv("TOKSCORE_TRACE_HOST")) {
+			uint32_t longest = 0, over1k = 0;
+			for (size_t j = 0; j < ns; j++) {
+				longest = std::max(longest, pb[j + 1] - pb[j]);
+				over1k += pb[j + 1] - pb[j] > 1024 ? 1 : 0;
+			}
+			fprintf(stderr, "plan_stream: %zu streams, longest %u bytes, %u over 1 KiB, %zu cuts dropped\n", ns, longest, over1k, unsynced);
+		}
 		std::vector<uint32_t> order(ns);
 		for (size_t j = 0; j < ns; j++) order[j] = (uint32_t)j;
 		std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return pb[x + 1] - pb[x] > pb[y + 1] - pb[y]; });
