@@ -108,10 +108,24 @@ def test_score_matches_oracle_on_synthetic(kind, nbytes, V):
         assert np.array_equal(counts, exp_counts), (kind, cfg)
 
 
-def test_wide_vocabulary_uses_32bit_stream():
-    # V + 3 > 32767 forces 32-bit stream entries (one histogram id range up to 40,000 ids, several above)
-    corpus, off = synth.random_utf8(1_000_000, seed=11, doc_lo=512, doc_hi=100_000)
-    tokens = synth.build_vocab(corpus, 40000)
+@pytest.mark.parametrize("kind", ["utf8", "wiki"])
+def test_wide_vocabulary_uses_32bit_stream(kind):
+    # V + 3 > 32767 forces 32-bit stream entries, counted in byte-wide LDS bins (kernels_tile.hip hist_kernel)
+    if kind == "utf8":
+        corpus, off = synth.random_utf8(1_000_000, seed=11, doc_lo=512, doc_hi=100_000)
+    else:
+        corpus, off = synth.wiki_like(3_000_000, seed=12)
+        # hot ids: some thousands of one token per workgroup, so that byte bins wrap (and wrap downwards
+        # when a re-score takes the old tokens out again)
+        docs = [corpus[off[i]:off[i + 1]].tobytes() for i in range(len(off) - 1)]
+        # (the third: the four ids of one bin word counted in step, so that a carry out of one byte finds
+        # its neighbour at the edge as well)
+        docs[3:3] = [b"zq" * 40000, b"z" * 30000 + b"qzq" * 9000, b"zqzq\x01zq\x01q\x01z\x01" * 20000]
+    tokens = synth.build_vocab(corpus[:1_000_000], 40000)
+    if kind == "wiki":
+        corpus, off = synth.pack_docs(docs)
+        tokens = [t for t in tokens if t not in (b"zq", b"zqzq", b"z", b"q")][:39990] + [b"z", b"q", b"zq", b"zqzq"]
+        assert (len(tokens) - 4 + 2) % 4 == 0   # ids of the last four: one word of byte bins
     # random text has too few repeated n-grams: top the list up with slices of the corpus
     text = corpus.tobytes().decode("utf-8")
     seen = set(tokens)
@@ -125,10 +139,37 @@ def test_wide_vocabulary_uses_32bit_stream():
     assert len(tokens) > 33000
     voc = O.OracleVocab(*synth.pack_vocab(tokens))
     exp = voc.score(corpus, off, threads=8)
-    (counts, tt, tb), info = _score_with({"TOKSCORE_SCAN": "tile"}, tokens, corpus, off)
-    assert info.scan_path == 1
-    assert (tt, tb) == exp[1:]
-    assert np.array_equal(counts, exp[0])
+    # byte bins in one id range, and in several narrow ones (range boundaries inside a word's neighbours)
+    for cfg in ({"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "tile", "TOKSCORE_HIST_RANGE": "9001"}):
+        (counts, tt, tb), info = _score_with(cfg, tokens, corpus, off)
+        assert info.scan_path == 1
+        assert (tt, tb) == exp[1:], cfg
+        assert np.array_equal(counts, exp[0]), cfg
+    # wiki: the hot ids pass 128 per workgroup many times over, the byte bins wrap and the wraps are booked
+    assert kind != "wiki" or int(exp[0][2:].max()) >= 20000
+    # re-scores after toggles subtract the old tokens of the selected chunks: bins move down and wrap downwards
+    s, old = _scorer({"TOKSCORE_SCAN": "tile"})
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        s.score()
+    finally:
+        _restore(old)
+    by_count = np.argsort(exp[0][2:len(tokens) + 2])[::-1]
+    hot = [int(k) for k in by_count if len(tokens[int(k)].decode("utf-8")) > 1][:3]
+    assert kind != "wiki" or len(tokens) - 1 in hot   # "zqzq": without it the same text is twice as many "zq"
+    assert hot
+    for i in hot:
+        s.toggle(i, False)
+    got = s.score(incremental=True)
+    sub = [b"\x00DISABLED" + str(k).encode() if k in hot else t for k, t in enumerate(tokens)]
+    exp2 = O.OracleVocab(*synth.pack_vocab(sub)).score(corpus, off, threads=8)
+    assert got[1:] == exp2[1:] and np.array_equal(got[0], exp2[0])
+    for i in hot:
+        s.toggle(i, True)
+    got = s.score(incremental=True)
+    assert got[1:] == exp[1:] and np.array_equal(got[0], exp[0])
+    s.close()
 
 
 def test_deep_128k_vocabulary_on_random_utf8():

@@ -43,6 +43,7 @@ struct TileScanPlan {
 	uint32_t lds_bytes;       // dynamic LDS per workgroup
 	uint32_t blocks;          // persistent workgroups
 	uint32_t wide_ids;        // 0: 16-bit stream entries, 1: 32-bit
+	uint32_t hist_range;      // most ids one histogram pass keeps bins for (0: what LDS holds)
 };
 // Token stream and work-queue words shared by the tile scan and the histogram.
 constexpr uint32_t kStreamBatch = 32;     // stream blocks handed out per allocation

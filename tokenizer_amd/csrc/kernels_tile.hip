@@ -684,12 +684,49 @@ __global__ void __launch_bounds__(1024) scan_tile_kernel(TrieDev T, CorpusDev C,
 }
 
 // ---- token stream -> counts ------------------------------------------------------------
-// grid = (slab_blocks, id_ranges); each workgroup keeps int32 bins for its id range in LDS,
-// consumes its share of the stream (16-byte vectors, null entries skipped), then stores the
-// bins to its slab row.
-template <bool WIDE>
+// grid = (slab_blocks, id_ranges); each workgroup keeps bins for its id range in LDS, consumes
+// its share of the stream (16-byte vectors, null entries skipped), then stores the bins to its
+// slab row as int32.
+//
+// 16-bit entries (V + 3 <= 32,767 ids): one int32 bin per id, one id range.
+// 32-bit entries: every id range is another pass over the whole stream (4 B per token: at
+// V = 131 k four passes with int32 bins were 24 % of an evaluation), so the bins are BYTES, four
+// to a word, 136 k ids per pass.  A bin is moved by returned 32-bit LDS atomics of +-(1 << 8j);
+// the word is exact modulo 2^32 whatever the order, so what has to be kept beside it is how
+// often each byte wrapped.  The operation whose returned value shows byte j at 0xFF before a +1
+// (0x00 before a -1) is the one that wrapped it -- each wrap is seen by exactly one operation,
+// atomics on a word being totally ordered -- and it notes the wrap (id, direction, how many
+// bytes up the word the carry ran) in a list in LDS.  Booking a wrap: [id_j] += +-256 and, since
+// the carry went into byte j+1, [id_j+1] -= +-1 -- in the workgroup's slab row when the list is
+// worked off at the end, in the output vector itself at once if the list is full.  At the end byte j holds
+// bias + count_j - 256 * wraps_j + wraps_(j-1), which is what the slab row plus the bookings add
+// up to.  Bins start near the end they move away from (0x10 counting up, 0xF0 for the
+// subtracting pass of a re-score; the few take-back entries move them the other way), so an id
+// needs 240 entries in one workgroup before its first wrap.
+constexpr uint32_t kWrapListBytes = 24 * 1024;
+__device__ __forceinline__ uint32_t wrapped_bytes(uint32_t old, uint32_t j, bool down) {
+	const uint32_t t = old >> (8 * j); // byte j and those above it; zeros shifted in
+	const uint32_t edge_run = down ? (t ? (uint32_t)__builtin_ctz(t) >> 3 : 4u) : (~t ? (uint32_t)__builtin_ctz(~t) >> 3 : 4u);
+	return edge_run < 4u - j ? edge_run : 4u - j;
+}
+template <typename T>
+__device__ __forceinline__ void book_wraps(uint32_t note, uint32_t lo, uint32_t hi, T *counts) {
+	// note = id << 3 | (bytes wrapped - 1) << 1 | down
+	const long long step = (note & 1u) ? -256 : 256, carry = (note & 1u) ? 1 : -1;
+	const uint32_t id = note >> 3, n = ((note >> 1) & 3u) + 1;
+	const uint32_t j = (id - lo) & 3u;
+	for (uint32_t t = 0; t < n && id + t < hi; t++) {
+		atomicAdd(&counts[id + t], (T)step);
+		if (j + t < 3 && id + t + 1 < hi) atomicAdd(&counts[id + t + 1], (T)carry);
+	}
+}
+__device__ __noinline__ void book_wraps_now(uint32_t note, uint32_t lo, uint32_t hi, unsigned long long *counts) {
+	book_wraps(note, lo, hi, counts);
+}
+
+template <bool WIDE, bool ONE_RANGE>
 __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids, uint32_t range_ids, uint32_t *slab,
-                                                    uint32_t flip) {
+                                                    unsigned long long *counts, uint32_t flip) {
 	using Q = QTraits<WIDE>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char tile_hist_smem[];
 	uint32_t *bins = reinterpret_cast<uint32_t *>(tile_hist_smem);
@@ -697,15 +734,21 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 	const uint32_t lo = blockIdx.y * range_ids;
 	const uint32_t hi = lo + range_ids < n_ids ? lo + range_ids : n_ids;
 	const uint32_t width = hi - lo;
-	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) bins[i] = 0;
-	if (threadIdx.x == 0) s_total = 0;
+	const uint32_t n_words = WIDE ? (width + 3) / 4 : width;
+	const uint32_t bias = flip ? 0xF0u : 0x10u;
+	for (uint32_t i = threadIdx.x; i < n_words + (WIDE ? 64u : 0u); i += blockDim.x) bins[i] = WIDE ? bias * 0x01010101u : 0u;
+	// (byte bins) the wrap list follows the bins and the lanes' spare words
+	__shared__ uint32_t s_wraps;
+	uint32_t *wrap_list = bins + n_words + 64;
+	constexpr uint32_t wrap_cap = kWrapListBytes / 4;
+	if (threadIdx.x == 0) s_total = 0, s_wraps = 0;
 	__syncthreads();
 	uint32_t batches = Qd.cursor[0];
 	if (batches > Qd.capacity_batches) batches = Qd.capacity_batches;
 	// The stream is read in rows of 64 vectors (1 KiB, one vector per lane); a block is one or
 	// two rows.  A wave takes every n-th batch: one look at fill[batch] (blocks past it were
-	// handed out but never written), then its rows kRowsInFlight at a time -- the loop is bound
-	// by the latency of these loads, not by the LDS atomics (without them: - 5 %).
+	// handed out but never written), then its rows kRowsInFlight at a time (16-bit entries: the loop
+	// is bound by the latency of these loads, not by the LDS atomics -- without them: - 5 %).
 	constexpr uint32_t vecs_per_block = 64 * kLogDepth * sizeof(typename Q::entry_t) / 16;
 	constexpr uint32_t rows_per_block = vecs_per_block / 64;
 	static_assert(vecs_per_block % 64 == 0, "a stream block is a whole number of 1 KiB rows");
@@ -715,31 +758,92 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 	const uint32_t wave_id = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6));
 	const uint4 *vec = reinterpret_cast<const uint4 *>(Qd.blocks);
 	int total = 0; // +1 / -1 per entry seen, whatever its id range
-	for (uint32_t bt = wave_id; bt < batches; bt += n_waves) {
-		uint32_t live = Qd.fill[bt];
-		if (live > kStreamBatch) live = kStreamBatch;
-		const uint32_t live_rows = __builtin_amdgcn_readfirstlane(live * rows_per_block);
-		const uint4 *rows = vec + (uint64_t)bt * kStreamBatch * vecs_per_block + lane;
-		for (uint32_t r0 = 0; r0 < live_rows; r0 += kRowsInFlight) {
-			uint4 v[kRowsInFlight];
+	if constexpr (WIDE) {
+		// Sixteen entries (four rows) at a time.  All their returned atomics go out before any
+		// result is looked at, and looking is branch-free (one bit per entry that wrapped its byte;
+		// one branch for the lot): a branch per entry, or per eight, cost more than the rest of the
+		// pass, which is bound by the instructions it issues and by the loads it keeps in flight
+		// (eight rows per wave; prefetching the next rows while counting lost: more registers
+		// than a wave of sixteen has).  With s = +1 / -1 the add is s << 8j at word id >> 2, and the
+		// byte wrapped iff old byte + s leaves 0..255, i.e. has bit 8 set.  A null entry or one
+		// outside the id range adds 0 to a spare word of the lane's own, which therefore stays at
+		// the bias and never looks wrapped.  (Variants measured on 157 M entries, this one 0.41 ms:
+		// no test for null, the word index clamped by min() instead, 0.45; two or three chunks of
+		// four rows refilled as they are counted, 0.46 - 0.53.  Plain adds without any wrap
+		// handling, which is not exact: 0.22.)
+		constexpr int kEntries = 16;
+		const uint32_t flip_bit = flip ? 0x80000000u : 0u;
+		for (uint32_t bt = wave_id; bt < batches; bt += n_waves) {
+			uint32_t live = Qd.fill[bt];
+			if (live > kStreamBatch) live = kStreamBatch;
+			const uint32_t live_rows = __builtin_amdgcn_readfirstlane(live * rows_per_block);
+			const uint4 *rows = vec + (uint64_t)bt * kStreamBatch * vecs_per_block + lane;
+			for (uint32_t r0 = 0; r0 < live_rows; r0 += kRowsInFlight) {
+				uint4 v[kRowsInFlight];
 #pragma unroll
-			for (int u = 0; u < kRowsInFlight; u++) {
-				v[u] = uint4{Q::null_word, Q::null_word, Q::null_word, Q::null_word};
-				if (r0 + u < live_rows) v[u] = rows[(size_t)(r0 + u) * 64];
+				for (int u = 0; u < kRowsInFlight; u++) {
+					v[u] = uint4{Q::null_word, Q::null_word, Q::null_word, Q::null_word};
+					if (r0 + u < live_rows) v[u] = rows[(size_t)(r0 + u) * 64];
+				}
+#pragma unroll
+				for (int half = 0; half < 4 * kRowsInFlight / kEntries; half++) {
+					uint32_t was[kEntries];
+#pragma unroll
+					for (int q = 0; q < kEntries; q++) {
+						const uint4 &vv = v[half * (kEntries / 4) + (q >> 2)];
+						const uint32_t e = (q & 3) == 0 ? vv.x : (q & 3) == 1 ? vv.y : (q & 3) == 2 ? vv.z : vv.w;
+						const int s_any = ((int)(e ^ flip_bit) >> 31) | 1;
+						const uint32_t b = (e & 0x7FFFFFFFu) - lo;
+						const bool mine = e != Q::null_word && (ONE_RANGE || b < width);
+						total += e != Q::null_word ? s_any : 0;
+						const int s = mine ? s_any : 0;
+						was[q] = atomicAdd(&bins[mine ? b >> 2 : n_words + lane], (uint32_t)s << (8 * (b & 3u)));
+					}
+					uint32_t wrapped = 0;
+#pragma unroll
+					for (int q = 0; q < kEntries; q++) {
+						const uint4 &vv = v[half * (kEntries / 4) + (q >> 2)];
+						const uint32_t e = (q & 3) == 0 ? vv.x : (q & 3) == 1 ? vv.y : (q & 3) == 2 ? vv.z : vv.w;
+						const int s = ((int)(e ^ flip_bit) >> 31) | 1;
+						const uint32_t j = (e - lo) & 3u;
+						wrapped |= ((((was[q] >> (8 * j)) & 0xFFu) + (uint32_t)s) >> 8 & 1u) << q;
+					}
+					if (__builtin_expect(wrapped != 0, 0)) {
+#pragma unroll
+						for (int q = 0; q < kEntries; q++) {
+							if (!((wrapped >> q) & 1u)) continue;
+							const uint4 &vv = v[half * (kEntries / 4) + (q >> 2)];
+							const uint32_t e = (q & 3) == 0 ? vv.x : (q & 3) == 1 ? vv.y : (q & 3) == 2 ? vv.z : vv.w;
+							const uint32_t id = e & 0x7FFFFFFFu, j = (id - lo) & 3u;
+							const bool down = ((e ^ flip_bit) >> 31) != 0;
+							const uint32_t note = id << 3 | (wrapped_bytes(was[q], j, down) - 1) << 1 | (down ? 1u : 0u);
+							const uint32_t at = atomicAdd(&s_wraps, 1u);
+							if (at < wrap_cap) wrap_list[at] = note;
+							else book_wraps_now(note, lo, hi, counts);
+						}
+					}
+				}
 			}
+		}
+	} else {
+		for (uint32_t bt = wave_id; bt < batches; bt += n_waves) {
+			uint32_t live = Qd.fill[bt];
+			if (live > kStreamBatch) live = kStreamBatch;
+			const uint32_t live_rows = __builtin_amdgcn_readfirstlane(live * rows_per_block);
+			const uint4 *rows = vec + (uint64_t)bt * kStreamBatch * vecs_per_block + lane;
+			for (uint32_t r0 = 0; r0 < live_rows; r0 += kRowsInFlight) {
+				uint4 v[kRowsInFlight];
 #pragma unroll
-			for (int u = 0; u < kRowsInFlight; u++) {
-				const uint32_t wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+				for (int u = 0; u < kRowsInFlight; u++) {
+					v[u] = uint4{Q::null_word, Q::null_word, Q::null_word, Q::null_word};
+					if (r0 + u < live_rows) v[u] = rows[(size_t)(r0 + u) * 64];
+				}
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
-					if (wds[k] == Q::null_word) continue;
-					if (WIDE) {
-						const uint32_t e = wds[k];
-						const uint32_t id = e & 0x7FFFFFFFu;
-						const int sgn = (((e & Q::neg) != 0) != (flip != 0)) ? -1 : 1;
-						total += sgn;
-						if (id >= lo && id < hi) atomicAdd(&bins[id - lo], (uint32_t)sgn);
-					} else {
+				for (int u = 0; u < kRowsInFlight; u++) {
+					const uint32_t wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						if (wds[k] == Q::null_word) continue;
 #pragma unroll
 						for (int h = 0; h < 2; h++) {
 							const uint32_t e = (wds[k] >> (16 * h)) & 0xFFFFu;
@@ -762,7 +866,17 @@ __global__ void __launch_bounds__(1024) hist_kernel(StreamDev Qd, uint32_t n_ids
 	}
 	__syncthreads();
 	uint32_t *row = slab + (size_t)blockIdx.x * (n_ids + 1);
-	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) row[lo + i] = bins[i];
+	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x)
+		row[lo + i] = WIDE ? (uint32_t)((int)((bins[i >> 2] >> (8 * (i & 3))) & 0xFFu) - (int)bias) : bins[i];
+	if (WIDE) {
+		// the noted wraps go into the workgroup's own slab row (once its stores have landed): the
+		// hot ids are neighbours, and 256 workgroups booking them in the output vector queued up on
+		// two or three cache lines (+ 0.4 ms per 157 M entries)
+		__threadfence();
+		__syncthreads();
+		const uint32_t noted = s_wraps < wrap_cap ? s_wraps : wrap_cap;
+		for (uint32_t i = threadIdx.x; i < noted; i += blockDim.x) book_wraps(wrap_list[i], lo, hi, row);
+	}
 	if (blockIdx.y == 0 && threadIdx.x == 0) row[n_ids] = (uint32_t)s_total;
 }
 
@@ -843,6 +957,8 @@ bool plan_tile_scan(const TrieDev &T, uint64_t max_len, uint32_t V, uint32_t num
 	plan->blocks = num_cus * per_cu;
 	if (const char *e = getenv("TOKSCORE_TILE_BLOCKS")) plan->blocks = (uint32_t)std::max(1, atoi(e)); // tests: a small grid
 	plan->wide_ids = wide;
+	plan->hist_range = 0;
+	if (const char *e = getenv("TOKSCORE_HIST_RANGE")) plan->hist_range = (uint32_t)std::max(64, atoi(e)); // tests: several id ranges
 	return true;
 }
 
@@ -884,21 +1000,23 @@ void launch_slab_reduce(const uint32_t *slab, uint32_t rows, uint32_t n_cols, un
 void launch_histogram(const StreamDev &Q, const TileScanPlan &plan, uint32_t V, unsigned long long *counts,
                       uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip) {
 	const uint32_t n_ids = V + 3;
-	// every id range is a pass over the whole stream: as few as the 160 KB of LDS allow, equal in size
-	constexpr uint32_t kMaxRange = 40000;
-	const uint32_t ranges = (n_ids + kMaxRange - 1) / kMaxRange;
-	const uint32_t range = (n_ids + ranges - 1) / ranges;
-	const uint32_t lds = range * 4;
+	// every id range is a pass over the whole stream: as few as the 160 KB of LDS allow, equal in
+	// size (int32 bins for 16-bit entries: always one range; byte bins for 32-bit entries)
+	uint32_t max_range = plan.wide_ids ? 136000u : 40000u;
+	if (plan.hist_range && plan.hist_range < max_range) max_range = plan.hist_range;
+	const uint32_t ranges = (n_ids + max_range - 1) / max_range;
+	const uint32_t range = (((n_ids + ranges - 1) / ranges) + 3) & ~3u; // whole words of byte bins
+	auto launch = [&](auto kernel, uint32_t lds) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(kernel, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab, counts,
+		                   flip ? 1u : 0u);
+	};
 	if (plan.wide_ids) {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_kernel<true>),
-		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(hist_kernel<true>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab,
-		                   flip ? 1u : 0u);
+		const uint32_t lds = range + 256 + kWrapListBytes; // + a spare word per lane + the wrap list
+		if (ranges == 1) launch(&hist_kernel<true, true>, lds);
+		else launch(&hist_kernel<true, false>, lds);
 	} else {
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_kernel<false>),
-		                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		hipLaunchKernelGGL(hist_kernel<false>, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, n_ids, range, slab,
-		                   flip ? 1u : 0u);
+		launch(&hist_kernel<false, false>, range * 4);
 	}
 	launch_slab_reduce(slab, slab_blocks, n_ids + 1, counts, stream);
 }
