@@ -105,3 +105,17 @@ def test_long_tokens_take_the_unprefetched_tile_path():
     got = _gpu_counts(names, (corpus, off), 1600)
     assert np.array_equal(got[0], exp[0]) and got[1] == exp[1]
     assert got[0][2] == 4  # the long one: documents 0 and 1, twice in document 4
+
+
+def test_one_workgroup_sees_more_than_a_16_bit_row_holds(monkeypatch):
+    # the slab rows of the slot histogram are 16 bits wide; a slot with more than 32,767 of one workgroup's
+    # entries is booked directly (kernels_stream.hip hist_slots_kernel)
+    monkeypatch.setenv("TOKSCORE_SLAB_BLOCKS", "1")
+    names = [b"a", b"b", b"ab", b"ba", b"abab"]
+    docs = [b"ab" * 50_000, b"b" * 40_000, b"ab"]
+    voc = O.OracleVocab(*synth.pack_vocab(names))
+    corpus, off = synth.pack_docs(docs)
+    exp = voc.count_occurrences(corpus, off, 4)
+    got = _gpu_counts(names, (corpus, off), 4)
+    assert int(exp[0].max()) > 40_000
+    assert np.array_equal(got[0], exp[0]) and got[1] == exp[1]

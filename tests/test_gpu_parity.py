@@ -186,6 +186,32 @@ def test_deep_128k_vocabulary_on_random_utf8():
         assert np.array_equal(counts, exp[0]), cfg
 
 
+def test_one_workgroup_sees_more_than_a_16_bit_row_holds():
+    # stream scan: slab rows are int16; bins that do not fit are booked directly, whichever way they count
+    tokens = [b"a", b"b", b"ab", b"abab", b"c"]
+    docs = [b"ab" * 70_000 + b"c", b"b" * 40_000, b"abab" * 3, b""]
+    corpus, off = synth.pack_docs(docs)
+    exp = O.OracleVocab(*synth.pack_vocab(tokens)).score(corpus, off)
+    assert int(exp[0].max()) > 32_767
+    (counts, tt, tb), info = _score_with({"TOKSCORE_SCAN": "stream", "TOKSCORE_SLAB_BLOCKS": "1"}, tokens, corpus, off)
+    assert info.scan_path == 2
+    assert (tt, tb) == exp[1:] and np.array_equal(counts, exp[0])
+    # and the subtracting pass of a re-score: "abab" off makes 70,000 "ab" of 35,000 "abab"
+    s, old = _scorer({"TOKSCORE_SCAN": "stream", "TOKSCORE_SLAB_BLOCKS": "1"})
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        s.score()
+        s.toggle(3, False)
+        got = s.score(incremental=True)
+    finally:
+        _restore(old)
+    sub = [t if k != 3 else b"\x00OFF" for k, t in enumerate(tokens)]
+    exp2 = O.OracleVocab(*synth.pack_vocab(sub)).score(corpus, off)
+    assert got[1:] == exp2[1:] and np.array_equal(got[0], exp2[0])
+    s.close()
+
+
 def test_empty_and_tiny_corpora():
     tokens = [b"a", b"b", b"ab"]
     for docs in ([], [b""], [b"", b"", b""], [b"a"], [b"", b"ab", b"", b"zab"]):

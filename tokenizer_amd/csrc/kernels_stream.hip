@@ -1370,11 +1370,23 @@ __device__ void fixup_ordered_pass(const FixDev &F) {
 	}
 }
 
+// a slot's count goes to the id the slot counts for; entries on slots nobody counts (document
+// separators) leave the token total again (main.cpp:41 counts the ids Tokenize returned, not the
+// separators this layout adds).  No map: counts per slot.
+__device__ __forceinline__ void book_slot(uint32_t s, long long sum, const uint32_t *slot_id, unsigned long long *out,
+                                          uint32_t total_index) {
+	const uint32_t id = slot_id ? slot_id[s] : s;
+	if (id == 0xFFFFFFFFu) atomicAdd(&out[total_index], (unsigned long long)(-sum));
+	else atomicAdd(&out[id], (unsigned long long)sum);
+}
+__host__ __device__ __forceinline__ uint32_t slab_row_stride(uint32_t nslots) { return (nslots + 1) & ~1u; } // int16 units
+
 // ---- token stream (slot indices) -> slab rows ----------------------------------------------
 // grid = (slab_blocks, slot ranges).  As hist_kernel (kernels_tile.hip), for u16 slot entries
 // (0xFFFF = null, no sign bit: a whole pass either adds or, with flip, subtracts).
-__global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t nslots, uint32_t range_slots,
-                                                          uint32_t *slab, uint32_t flip) {
+__global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t nslots, uint32_t range_slots, int16_t *slab,
+                                                          uint32_t flip, const uint32_t *slot_id, unsigned long long *out,
+                                                          uint32_t total_index) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char hist_smem[];
 	uint32_t *bins = reinterpret_cast<uint32_t *>(hist_smem);
 	__shared__ int s_total;
@@ -1439,49 +1451,58 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 		if ((threadIdx.x & 63) == 0 && total != 0) atomicAdd(&s_total, total);
 	}
 	__syncthreads();
-	uint32_t *row = slab + (size_t)blockIdx.x * (nslots + 1);
-	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) row[lo + i] = bins[i];
-	if (blockIdx.y == 0 && threadIdx.x == 0) row[nslots] = (uint32_t)s_total;
+	// The slab row is 16 bits per slot (half the bytes written here and read by the reduction: at
+	// 37.8 k slots and 256 workgroups 2 x 19 MB per evaluation).  A bin that does not fit -- one
+	// slot with more than 32,767 of a workgroup's entries -- goes to the output directly, as the
+	// reduction would have booked it; so does the workgroup's entry count.
+	int16_t *row = slab + (size_t)blockIdx.x * slab_row_stride(nslots);
+	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) {
+		const int v = (int)bins[i];
+		const bool fits = v >= -32768 && v <= 32767;
+		row[lo + i] = fits ? (int16_t)v : (int16_t)0;
+		if (!fits) book_slot(lo + i, (long long)v, slot_id, out, total_index);
+	}
+	if (blockIdx.y == 0 && threadIdx.x == 0 && s_total != 0) atomicAdd(&out[total_index], (unsigned long long)(long long)s_total);
 }
 
-// Slab rows (int32 partials per slot, column nslots = entries seen) -> out: counts[slot_id[s]] +=
-// column sums; entries on slots nobody counts (document separators) leave the token total again
-// (main.cpp:41 counts the ids Tokenize returned, not the separators this layout adds).
-// One workgroup = 64 columns x 16 row groups: wave w sums the rows r = w, w + 16, ... of its 64
-// columns (256 contiguous bytes per row), the partials meet in LDS, and wave 0 adds each column's
-// total to the id its slot counts for -- one scattered 64-bit atomic per slot and evaluation.
+// Slab rows (int16 partials per slot) -> out: counts[slot_id[s]] += column sums (book_slot).
+// One workgroup = 128 columns x 16 row groups: wave w sums the rows r = w, w + 16, ... of its 128
+// columns (two to a lane, 256 contiguous bytes per row), the partials meet in LDS, and wave 0 adds
+// each column's total to the id its slot counts for -- one scattered 64-bit atomic per slot and
+// evaluation.
 constexpr uint32_t kMapReduceGroups = 16;
-__global__ void __launch_bounds__(1024) slab_reduce_map_kernel(const uint32_t *slab, uint32_t rows, uint32_t nslots,
+__global__ void __launch_bounds__(1024) slab_reduce_map_kernel(const int16_t *slab, uint32_t rows, uint32_t nslots,
                                                                const uint32_t *slot_id, unsigned long long *out,
                                                                uint32_t total_index) {
-	__shared__ long long part[kMapReduceGroups][64];
+	__shared__ int part[kMapReduceGroups][64][2];
 	const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-	const uint32_t s = blockIdx.x * 64 + lane;
-	const size_t stride = (size_t)nslots + 1;
-	long long sum = 0;
-	if (s <= nslots) {
+	const uint32_t s = blockIdx.x * 128 + lane * 2;
+	const size_t stride = slab_row_stride(nslots) / 2; // in 32-bit words
+	const uint32_t *slab2 = reinterpret_cast<const uint32_t *>(slab);
+	int lo = 0, hi = 0; // (rows x 32,767 fits easily)
+	if (s < nslots) {
 		uint32_t r = grp;
 		for (; r + 3 * kMapReduceGroups < rows; r += 4 * kMapReduceGroups) {
-			const int32_t a0 = (int32_t)slab[(size_t)r * stride + s];
-			const int32_t a1 = (int32_t)slab[(size_t)(r + kMapReduceGroups) * stride + s];
-			const int32_t a2 = (int32_t)slab[(size_t)(r + 2 * kMapReduceGroups) * stride + s];
-			const int32_t a3 = (int32_t)slab[(size_t)(r + 3 * kMapReduceGroups) * stride + s];
-			sum += (long long)a0 + a1 + a2 + a3;
+			const uint32_t a0 = slab2[(size_t)r * stride + s / 2];
+			const uint32_t a1 = slab2[(size_t)(r + kMapReduceGroups) * stride + s / 2];
+			const uint32_t a2 = slab2[(size_t)(r + 2 * kMapReduceGroups) * stride + s / 2];
+			const uint32_t a3 = slab2[(size_t)(r + 3 * kMapReduceGroups) * stride + s / 2];
+			lo += (int)(int16_t)a0 + (int)(int16_t)a1 + (int)(int16_t)a2 + (int)(int16_t)a3;
+			hi += ((int)a0 >> 16) + ((int)a1 >> 16) + ((int)a2 >> 16) + ((int)a3 >> 16);
 		}
-		for (; r < rows; r += kMapReduceGroups) sum += (long long)(int32_t)slab[(size_t)r * stride + s];
+		for (; r < rows; r += kMapReduceGroups) {
+			const uint32_t a = slab2[(size_t)r * stride + s / 2];
+			lo += (int)(int16_t)a;
+			hi += (int)a >> 16;
+		}
 	}
-	part[grp][lane] = sum;
+	part[grp][lane][0] = lo;
+	part[grp][lane][1] = hi;
 	__syncthreads();
-	if (grp != 0 || s > nslots) return;
-	for (uint32_t g = 1; g < kMapReduceGroups; g++) sum += part[g][lane];
-	if (sum == 0) return;
-	if (s == nslots) {
-		atomicAdd(&out[total_index], (unsigned long long)sum);
-		return;
-	}
-	const uint32_t id = slot_id ? slot_id[s] : s; // (no map: counts per slot)
-	if (id == 0xFFFFFFFFu) atomicAdd(&out[total_index], (unsigned long long)(-sum));
-	else atomicAdd(&out[id], (unsigned long long)sum);
+	if (grp != 0 || s >= nslots) return;
+	for (uint32_t g = 1; g < kMapReduceGroups; g++) lo += part[g][lane][0], hi += part[g][lane][1];
+	if (lo != 0) book_slot(s, lo, slot_id, out, total_index);
+	if (hi != 0 && s + 1 < nslots) book_slot(s + 1, hi, slot_id, out, total_index);
 }
 
 } // namespace
@@ -1694,11 +1715,12 @@ void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t 
 	const uint32_t ranges = (nslots + kMaxRange - 1) / kMaxRange;
 	const uint32_t range = (nslots + ranges - 1) / ranges;
 	const uint32_t lds = range * 4;
+	int16_t *rows = reinterpret_cast<int16_t *>(slab); // slab_blocks rows of slab_row_stride(nslots) int16
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_slots_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 	                          (int)lds);
-	hipLaunchKernelGGL(hist_slots_kernel, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, nslots, range, slab,
-	                   flip ? 1u : 0u);
-	hipLaunchKernelGGL(slab_reduce_map_kernel, dim3((nslots + 1 + 63) / 64), dim3(64 * kMapReduceGroups), 0, stream, slab,
+	hipLaunchKernelGGL(hist_slots_kernel, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, nslots, range, rows,
+	                   flip ? 1u : 0u, slot_id, out, total_index);
+	hipLaunchKernelGGL(slab_reduce_map_kernel, dim3((nslots + 127) / 128), dim3(64 * kMapReduceGroups), 0, stream, rows,
 	                   slab_blocks, nslots, slot_id, out, total_index);
 }
 
