@@ -1384,16 +1384,22 @@ __host__ __device__ __forceinline__ uint32_t slab_row_stride(uint32_t nslots) { 
 // ---- token stream (slot indices) -> slab rows ----------------------------------------------
 // grid = (slab_blocks, slot ranges).  As hist_kernel (kernels_tile.hip), for u16 slot entries
 // (0xFFFF = null, no sign bit: a whole pass either adds or, with flip, subtracts).
+// The loop is bound by the instructions it issues (23 per entry with a test and a branch for
+// null, a range test and a count of the entries seen: 14 us of the kernel's 20 on the bench
+// shard), so with one slot range there is none of that per entry: the index is min(entry,
+// width + lane), which sends a null entry to a spare word of the lane's own, and the entries seen
+// are the entries looked at minus what the spare words collected.
+template <bool ONE_RANGE>
 __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t nslots, uint32_t range_slots, int16_t *slab,
                                                           uint32_t flip, const uint32_t *slot_id, unsigned long long *out,
                                                           uint32_t total_index) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char hist_smem[];
 	uint32_t *bins = reinterpret_cast<uint32_t *>(hist_smem);
 	__shared__ int s_total;
-	const uint32_t lo = blockIdx.y * range_slots;
+	const uint32_t lo = ONE_RANGE ? 0u : blockIdx.y * range_slots;
 	const uint32_t hi = lo + range_slots < nslots ? lo + range_slots : nslots;
 	const uint32_t width = hi - lo;
-	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) bins[i] = 0;
+	for (uint32_t i = threadIdx.x; i < width + 64; i += blockDim.x) bins[i] = 0;
 	if (threadIdx.x == 0) s_total = 0;
 	__syncthreads();
 	uint32_t batches = Qd.cursor[0];
@@ -1405,7 +1411,8 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 	const uint32_t wave_id = uni32(blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6));
 	const uint4 *vec = reinterpret_cast<const uint4 *>(Qd.blocks);
 	const uint32_t sgn = flip ? 0xFFFFFFFFu : 1u;
-	uint32_t seen = 0;
+	const uint32_t spare = width + lane;
+	uint32_t seen = 0; // ONE_RANGE: entries looked at, null or not
 	for (uint32_t bt = wave_id; bt < batches; bt += n_waves) {
 		uint32_t live = Qd.fill[bt]; // entries written to the batch (what follows them was never written)
 		if (live > kBatchEntries) live = kBatchEntries;
@@ -1428,18 +1435,32 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 					}
 				}
 			}
+			if constexpr (ONE_RANGE) {
+				seen += 8 * kRowsInFlight;
 #pragma unroll
-			for (int u = 0; u < kRowsInFlight; u++) {
-				const uint32_t wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+				for (int u = 0; u < kRowsInFlight; u++) {
+					const uint32_t wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
-				for (int k = 0; k < 4; k++) {
-					if (wds[k] == 0xFFFFFFFFu) continue;
+					for (int k = 0; k < 4; k++) {
+						const uint32_t e0 = wds[k] & 0xFFFFu, e1 = wds[k] >> 16;
+						atomicAdd(&bins[e0 < spare ? e0 : spare], sgn);
+						atomicAdd(&bins[e1 < spare ? e1 : spare], sgn);
+					}
+				}
+			} else {
 #pragma unroll
-					for (int h = 0; h < 2; h++) {
-						const uint32_t e = (wds[k] >> (16 * h)) & 0xFFFFu;
-						if (e == 0xFFFFu) continue;
-						seen++;
-						if (e >= lo && e < hi) atomicAdd(&bins[e - lo], sgn);
+				for (int u = 0; u < kRowsInFlight; u++) {
+					const uint32_t wds[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						if (wds[k] == 0xFFFFFFFFu) continue;
+#pragma unroll
+						for (int h = 0; h < 2; h++) {
+							const uint32_t e = (wds[k] >> (16 * h)) & 0xFFFFu;
+							if (e == 0xFFFFu) continue;
+							seen++;
+							if (e >= lo && e < hi) atomicAdd(&bins[e - lo], sgn);
+						}
 					}
 				}
 			}
@@ -1451,6 +1472,11 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 		if ((threadIdx.x & 63) == 0 && total != 0) atomicAdd(&s_total, total);
 	}
 	__syncthreads();
+	if (ONE_RANGE && threadIdx.x < 64) { // the null entries were looked at, not seen (flip: both counts are negative)
+		int nulls = (int)bins[width + threadIdx.x];
+		for (int o = 32; o > 0; o >>= 1) nulls += __shfl_down(nulls, o, 64);
+		if (threadIdx.x == 0) s_total -= nulls;
+	}
 	// The slab row is 16 bits per slot (half the bytes written here and read by the reduction: at
 	// 37.8 k slots and 256 workgroups 2 x 19 MB per evaluation).  A bin that does not fit -- one
 	// slot with more than 32,767 of a workgroup's entries -- goes to the output directly, as the
@@ -1462,6 +1488,7 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 		row[lo + i] = fits ? (int16_t)v : (int16_t)0;
 		if (!fits) book_slot(lo + i, (long long)v, slot_id, out, total_index);
 	}
+	__syncthreads();
 	if (blockIdx.y == 0 && threadIdx.x == 0 && s_total != 0) atomicAdd(&out[total_index], (unsigned long long)(long long)s_total);
 }
 
@@ -1714,12 +1741,15 @@ void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t 
 	constexpr uint32_t kMaxRange = 40000;
 	const uint32_t ranges = (nslots + kMaxRange - 1) / kMaxRange;
 	const uint32_t range = (nslots + ranges - 1) / ranges;
-	const uint32_t lds = range * 4;
+	const uint32_t lds = (range + 64) * 4; // + a spare word per lane
 	int16_t *rows = reinterpret_cast<int16_t *>(slab); // slab_blocks rows of slab_row_stride(nslots) int16
-	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&hist_slots_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-	                          (int)lds);
-	hipLaunchKernelGGL(hist_slots_kernel, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, nslots, range, rows,
-	                   flip ? 1u : 0u, slot_id, out, total_index);
+	auto go = [&](auto kernel) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(kernel, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, nslots, range, rows, flip ? 1u : 0u,
+		                   slot_id, out, total_index);
+	};
+	if (ranges == 1) go(&hist_slots_kernel<true>);
+	else go(&hist_slots_kernel<false>);
 	hipLaunchKernelGGL(slab_reduce_map_kernel, dim3((nslots + 127) / 128), dim3(64 * kMapReduceGroups), 0, stream, rows,
 	                   slab_blocks, nslots, slot_id, out, total_index);
 }
