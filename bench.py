@@ -345,12 +345,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # HIP events, recorded by the library on the stream its kernels run on and read after the timed
+    # region (no host sync inside it): around the scan kernel of every 4th timed launch.  Marking
+    # every launch, and every kernel of it, costs 8 % of a step (a record holds the stream for
+    # 3 - 4 us; tools/dbg/ab_steps.py), which a caller without a profiler does not pay.
+    sample_every = 4 if args.steps >= 8 else 1
+    scorer.set_timing(2, sample_every)
     elapsed = timed_steps(step, fence, args.steps, args.warmup, after_warmup=scorer.drain_timings)
-    # HIP events the library recorded around its kernels, on the stream they ran on,
-    # for exactly the K timed steps (read after the region: no host sync inside it)
-    tm = scorer.drain_timings()[-args.steps:]
-    eval_ms = [t[0] for t in tm]
-    scan_ms = [t[1] for t in tm]
+    scan_ms = [t[1] for t in scorer.drain_timings()]
+    # the whole evaluation's kernels, every one marked: five launches after the timed region
+    scorer.set_timing(1)
+    for _ in range(5):
+        scorer.score_async(out.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    eval_ms = [t[0] for t in scorer.drain_timings()]
     elapsed = max_over_ranks(elapsed, dist_mod, ranks_in_exchange, "cpu" if rehearsal else dev)
     # what d_out cannot show: a token-stream overflow of the last asynchronous evaluation
     overflowed = scorer.async_status(stream.cuda_stream)
@@ -393,7 +401,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": {1: "scan_tile_kernel", 2: "scan_ranges_kernel"}.get(int(info.scan_path), "scan_generic_kernel"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": scan_avg_ms,
+                         "kernel_ms_from": "HIP events around %d of the %d timed launches (every %s)"
+                                           % (len(scan_ms), args.steps, "one" if sample_every == 1 else "%dth" % sample_every),
                          "eval_kernels_ms": float(np.mean(eval_ms)),
+                         "eval_kernels_ms_from": "5 launches after the timed region, every kernel marked",
                          "measured_stream_read_GBps": {"hbm_4GiB": stream_hbm, "shard_sized_buffer": stream_shard},
                          "frac_of_measured_hbm_stream": achieved / stream_hbm if stream_hbm else None},
             "total_tokens": int(host[V + 3]), "h2d_inclusive_GBps": info.corpus_bytes / (h2d_s + elapsed / args.steps) / 1e9,

@@ -224,6 +224,14 @@ int tokscore_last_timing(tokscore_ctx *ctx, float ms[4]);
  * floats; *n receives the number of calls reported. */
 int tokscore_drain_timings(tokscore_ctx *ctx, float *ms, uint32_t cap, uint32_t *n);
 
+/* Measurement aid; no counterpart in the reference.  Which HIP events tokscore_score_async and
+ * tokscore_score record: mode 0 none, 1 all (the default; TOKSCORE_TIMING=0 starts a context at 0),
+ * 2 only the two around the scan kernel, and only on every `every`-th full evaluation (0 = 1) --
+ * the other evaluations carry none and are not reported by tokscore_drain_timings; a reported one
+ * has [0] = [1] = the scan kernel, [2] = [3] = 0.  An event record holds the stream for 3 - 4 us,
+ * so a benchmark that times many evaluations back to back samples instead of marking every one. */
+int tokscore_set_timing(tokscore_ctx *ctx, int mode, uint32_t every);
+
 /* Measurement aid ("report against a measured read-only streaming kernel
  * on the same box"); no counterpart in the reference.  Reads a zeroed scratch buffer of `bytes`
  * (>= 1 MiB; allocated and freed inside) `reps` times with a kernel that only loads, and

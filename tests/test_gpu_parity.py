@@ -440,6 +440,45 @@ def test_stream_overflow_is_reported_or_rescued():
             out.free()
 
 
+@pytest.mark.parametrize("path", ["stream", "tile"])
+def test_sampled_timing_marks_every_nth_evaluation_and_changes_no_result(path):
+    """tokscore_set_timing: mode 2 records the two events around the scan kernel on every n-th full
+    evaluation only; the results are what they are with every kernel marked, or with none."""
+    corpus, off = synth.wiki_like(600_000, seed=21)
+    tokens = synth.build_vocab(corpus[:300_000], 3000)
+    V = len(tokens)
+    exp = O.OracleVocab(*synth.pack_vocab(tokens)).score(corpus, off, threads=8)
+    s, old = _scorer({"TOKSCORE_SCAN": path})
+    out = None
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        out = _DeviceBuffer((V + 5) * 8)
+        s.score_async(out.ptr.value)
+        assert s.async_status() is False
+        s.drain_timings()
+        for mode, every, marked in ((2, 4, 3), (0, 1, 0), (1, 1, 10), (2, 1, 10)):
+            s.set_timing(mode, every)
+            for _ in range(10):
+                s.score_async(out.ptr.value)
+            assert s.async_status() is False
+            got = out.to_host()
+            assert np.array_equal(got[:V + 3], exp[0]) and int(got[V + 3]) == exp[1] and int(got[V + 4]) == exp[2]
+            tm = s.drain_timings()
+            assert len(tm) == marked, (mode, every, len(tm))
+            for t in tm:
+                assert t[1] > 0
+                if mode == 2:
+                    assert t[0] == t[1] and t[2] == 0 and t[3] == 0
+                else:
+                    assert t[0] >= t[1]
+    finally:
+        _restore(old)
+        s.close()
+        if out:
+            out.free()
+
+
 @pytest.mark.gpu
 def test_bench_exchange_runs_over_rccl_on_one_rank():
     """bench.py's N > 1 exchange (score_async, then all_reduce of the u64 vector on the same stream,

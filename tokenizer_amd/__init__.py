@@ -61,6 +61,7 @@ _SIGNATURES = [
     ("tokscore_get_info", C.c_int, [C.c_void_p, C.POINTER(TokscoreInfo)]),
     ("tokscore_last_timing", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("tokscore_drain_timings", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("tokscore_set_timing", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     ("tokscore_hosttrie_longest", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u64p]),
     ("tokscore_probe_read_bandwidth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
 ]
@@ -247,6 +248,11 @@ class Scorer:
         ms = (C.c_float * 4)()
         self._check(self._lib.tokscore_last_timing(self._h, ms))
         return [float(x) for x in ms]
+
+    def set_timing(self, mode: int, every: int = 1):
+        """0: no HIP events; 1: all of them (the default); 2: the two around the scan kernel, on every
+        `every`-th full evaluation only (tokscore_set_timing)."""
+        self._check(self._lib.tokscore_set_timing(self._h, int(mode), int(every)))
 
     def drain_timings(self, cap: int = 256):
         """[(eval, scan, fixup, hist+reduce) ms] for every score call since the last drain."""

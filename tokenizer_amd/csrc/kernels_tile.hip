@@ -48,7 +48,6 @@ template <> struct QTraits<false> {
 template <> struct QTraits<true> {
 	using entry_t = uint32_t;
 	static constexpr uint32_t neg = 0x80000000u;
-	static constexpr uint32_t null_entry = 0x7FFFFFFFu;
 	static constexpr uint32_t null_word = 0x7FFFFFFFu;
 };
 

@@ -86,6 +86,12 @@ struct tokscore_ctx {
 	// (every record costs about 5 us of stream time) and reads 0 = 1, 3 = 2
 	hipEvent_t view[kRing][5] = {};
 	bool timing_on = true;      // TOKSCORE_TIMING=0: no events at all
+	// tokscore_set_timing: events around the scan kernel only, on every timing_every-th full
+	// evaluation (an event record holds the stream for 3 - 4 us: three per evaluation are 8 % of
+	// one on the bench shard)
+	bool timing_scan_only = false;
+	uint32_t timing_every = 1;
+	uint64_t timing_skipped = 0;
 	bool timing_detail = false; // TOKSCORE_TIMING=2: the incremental re-score records its passes too
 	hipEvent_t *ev = ring[0];
 	uint64_t calls = 0;   // score calls enqueued
@@ -833,17 +839,18 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	// 5 us, so the evaluation start shares the scan-start event (prepare_kernel, 4 us, is outside)
 	// and without fix-up kernels the "fix-up" interval is empty.
 	hipEvent_t *ev = nullptr, *view = nullptr;
-	if (c->timing_on) {
+	const bool scan_only = c->timing_scan_only;
+	if (c->timing_on && (!scan_only || c->timing_skipped++ % c->timing_every == 0)) {
 		ev = c->ring[c->calls % tokscore_ctx::kRing];
 		view = c->view[c->calls % tokscore_ctx::kRing];
 		c->calls++;
 		view[0] = view[1] = ev[1];
 		view[2] = ev[2];
-		view[3] = repair ? ev[3] : ev[2];
-		view[4] = ev[4];
+		view[3] = repair && !scan_only ? ev[3] : ev[2];
+		view[4] = scan_only ? ev[2] : ev[4];
 		c->ev = view;
 	}
-	auto mark = [&](int k) -> hipError_t { return ev ? hipEventRecord(ev[k], s) : hipSuccess; };
+	auto mark = [&](int k) -> hipError_t { return ev && (!scan_only || k == 1 || k == 2) ? hipEventRecord(ev[k], s) : hipSuccess; };
 	if (c->scan_path == 2) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s, c->d_tprep ? c->rplan.blocks * c->rplan.waves_per_block : 0u);
@@ -1974,6 +1981,15 @@ int tokscore_last_timing(tokscore_ctx *c, float ms[4]) {
 		c->timing_pending = false;
 	}
 	memcpy(ms, c->last_ms, sizeof c->last_ms);
+	return TOKSCORE_OK;
+}
+
+int tokscore_set_timing(tokscore_ctx *c, int mode, uint32_t every) {
+	if (!c || mode < 0 || mode > 2) return TOKSCORE_E_ARG;
+	c->timing_on = mode != 0;
+	c->timing_scan_only = mode == 2;
+	c->timing_every = every ? every : 1;
+	c->timing_skipped = 0;
 	return TOKSCORE_OK;
 }
 
