@@ -904,6 +904,20 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 // the previous lookup; v25-v29, s[38:43] scratch.  The block is entered and left at the start of a
 // round: left when no lane is active any more or when the stream batch may not take another round
 // (the C++ around it opens the next batch and comes back), with nothing in flight.
+// Timing experiments on the round loop (csrc/Makefile `exp`, tools/dbg/ab_libs.sh; never in the product
+// library): TOK_EXP_NOSTORE drops the token store (results wrong, the scan 2 % faster: the store is not
+// what the loop waits for); TOK_EXP_EXTRA_RT puts one more dependent LDS read in front of every
+// lookup (results unchanged, + 11 %: what a round trip on the chain costs).
+#ifdef TOK_EXP_NOSTORE
+#define TOK_EXP_STORE ""
+#else
+#define TOK_EXP_STORE "global_store_short v26, %[lslot], %[sbase]\n s_bcnt1_i32_b64 s40, exec\n s_lshl1_add_u32 %[cur], s40, %[cur]\n"
+#endif
+#ifdef TOK_EXP_EXTRA_RT
+#define TOK_EXP_CHAIN "ds_read_u8 v26, v24\n s_waitcnt lgkmcnt(0)\n v_and_b32 v26, 0, v26\n v_or_b32 v24, v24, v26\n"
+#else
+#define TOK_EXP_CHAIN ""
+#endif
 #define TOK_RANGES_ASM(K, HIGH)                                                              \
 	asm volatile(                                                                             \
 	    "s_mov_b64 s[38:39], exec\n"                                                          \
@@ -935,6 +949,7 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    ".rept " #K "\n"                                                                      \
 	    "s_waitcnt lgkmcnt(0)\n"                                                              \
 	    "s_setprio 2\n"                               /* the dependent part of a lookup goes before other waves' logging */ \
+	    TOK_EXP_CHAIN                                                                         \
 	    "v_add_u32 v25, %[nb], v24\n"                 /* slot t = LDS address of lt[t]     */ \
 	    "v_lshl_add_u32 v26, v25, 1, %[basea]\n"      /* address of base[t]                */ \
 	    "ds_read_u8 v27, v25\n"                                                               \
@@ -958,9 +973,7 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "v_mbcnt_lo_u32_b32 v26, exec_lo, 0\n"                                                \
 	    "v_mbcnt_hi_u32_b32 v26, exec_hi, v26\n"      /* rank among them                   */ \
 	    "v_lshl_add_u32 v26, v26, 1, %[cur]\n"        /* byte offset in the wave's stream batch */ \
-	    "global_store_short v26, %[lslot], %[sbase]\n"                                        \
-	    "s_bcnt1_i32_b64 s40, exec\n"                                                         \
-	    "s_lshl1_add_u32 %[cur], s40, %[cur]\n"                                               \
+	    TOK_EXP_STORE                                                                         \
 	    "v_cmp_ge_u32 vcc, %[cp], %[hi]\n"            /* range done                        */ \
 	    "s_andn2_b64 %[act], %[act], vcc\n"                                                   \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
