@@ -918,6 +918,19 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 #else
 #define TOK_EXP_CHAIN ""
 #endif
+#if defined(TOK_EXP_EXTRA_RANDOM)
+#define TOK_EXP_READ "ds_read_u8 v30, v26\n" /* one more independent read at a random address */
+#elif defined(TOK_EXP_EXTRA_BCAST)
+#define TOK_EXP_READ "v_mov_b32 v30, 0\n ds_read_u8 v30, v30\n" /* ... at one address for all lanes */
+#else
+#define TOK_EXP_READ ""
+#endif
+// LDS address of ring byte POS: dword row (POS / 4) mod (RING / 4) of the wave's ring block (256 bytes a
+// row: a dword per lane, so whatever positions the lanes are at they read 64 different banks), byte POS mod 4
+#define TOK_RING_BYTE_ADDR(DST, POS)                                                         \
+	"v_and_b32 " DST ", %[rrows], " POS "\n"                                                 \
+	"v_lshl_add_u32 " DST ", " DST ", 6, %[rbase]\n"                                         \
+	"v_and_or_b32 " DST ", " POS ", 3, " DST "\n"
 #define TOK_RANGES_ASM(K, HIGH)                                                              \
 	asm volatile(                                                                             \
 	    "s_mov_b64 s[38:39], exec\n"                                                          \
@@ -925,7 +938,7 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "s_mov_b64 %[req], %[reqin]\n"                                                        \
 	    "s_mov_b32 %[cur], %[curin]\n"                                                        \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
-	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
+	    TOK_RING_BYTE_ADDR("v25", "%[cp]")                                                    \
 	    "ds_read_u8 v24, v25\n"                                                               \
 	    ".Lround%=:\n"                                /* refill, then a round of K lookups */ \
 	    "s_cmp_eq_u64 %[act], 0\n"                                                            \
@@ -934,8 +947,9 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "s_cbranch_scc1 .Lout%=\n"                                                            \
 	    "s_waitcnt vmcnt(4)\n"                        /* (in issue order: the piece came before the round's >= 4 stores) */ \
 	    "s_mov_b64 exec, %[req]\n"                    /* the piece asked for a round ago   */ \
-	    "v_and_or_b32 v25, %[fill], %[rmask], %[rbase]\n"                                     \
-	    "ds_write_b64 v25, %[data]\n"                                                         \
+	    "v_and_b32 v25, %[rmask], %[fill]\n"          /* (a multiple of 8: dword rows 2 j, 2 j + 1) */ \
+	    "v_lshl_add_u32 v25, v25, 6, %[rbase]\n"                                              \
+	    "ds_write2st64_b32 v25, %[d0], %[d1] offset1:1\n"                                     \
 	    "v_add_u32 %[fill], 8, %[fill]\n"                                                     \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
 	    "v_sub_u32 v25, %[fill], %[lend]\n"                                                   \
@@ -943,8 +957,9 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "s_mov_b64 %[req], vcc\n"                                                             \
 	    "s_mov_b64 exec, vcc\n"                                                               \
 	    "v_lshl_add_u32 v25, %[fill], 6, %[tb]\n"                                             \
-	    "s_waitcnt lgkmcnt(0)\n"                      /* (data is free again)              */ \
-	    "global_load_dwordx2 %[data], v25, %[tprep]\n"                                        \
+	    "s_waitcnt lgkmcnt(0)\n"                      /* (d0, d1 are free again)           */ \
+	    "global_load_dword %[d0], v25, %[tprep]\n"                                            \
+	    "global_load_dword %[d1], v25, %[tprep] offset:4\n"                                   \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
 	    ".rept " #K "\n"                                                                      \
 	    "s_waitcnt lgkmcnt(0)\n"                                                              \
@@ -954,6 +969,7 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "v_lshl_add_u32 v26, v25, 1, %[basea]\n"      /* address of base[t]                */ \
 	    "ds_read_u8 v27, v25\n"                                                               \
 	    "ds_read_u16 v28, v26\n"                                                              \
+	    TOK_EXP_READ                                                                          \
 	    "v_add_u32 v29, 1, %[cp]\n"                                                           \
 	    "s_waitcnt lgkmcnt(0)\n"                                                              \
 	    "v_xor_b32 v27, v27, v24\n"                   /* 0x80 hit on a token end, 0 hit    */ \
@@ -966,7 +982,7 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "s_and_b64 s[40:41], vcc, s[42:43]\n"         /* the token goes on                 */ \
 	    "v_cndmask_b32 %[cp], %[lend], v29, s[40:41]\n" /* ... or the next token starts at lend */ \
 	    "v_cndmask_b32 %[nb], 0, v28, s[40:41]\n"     /* token complete: 0 = the root again */ \
-	    "v_and_or_b32 v25, %[cp], %[rmask], %[rbase]\n"                                       \
+	    TOK_RING_BYTE_ADDR("v25", "%[cp]")                                                    \
 	    "ds_read_u8 v24, v25\n"                                                               \
 	    "s_setprio 0\n"                                                                       \
 	    "s_andn2_b64 exec, exec, s[40:41]\n"          /* lanes whose token is complete     */ \
@@ -983,11 +999,11 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                     \
 	    "s_mov_b64 exec, s[38:39]\n"                                                          \
 	    : [cp] "+v"(cp), [nb] "+v"(nb), [lend] "+v"(lend), [lslot] "+v"(lslot), [fill] "+v"(fill),      \
-	      [data] "+v"(data), [act] "=&s"(act_out), [req] "=&s"(req_out), [cur] "=&s"(cur_out)           \
+	      [d0] "+v"(data0), [d1] "+v"(data1), [act] "=&s"(act_out), [req] "=&s"(req_out), [cur] "=&s"(cur_out)           \
 	    : [actin] "s"(uni64(act)), [reqin] "s"(uni64(req)), [curin] "s"(uni32(log.cur)), [sbase] "s"(uni64((unsigned long long)(uintptr_t)log.base)), \
-	      [hi] "v"(end), [rbase] "v"(ring_a), [tb] "v"(tb), [rmask] "s"(RING - 1), [basea] "s"(label_bytes), \
+	      [hi] "v"(end), [rbase] "v"(ring_a), [tb] "v"(tb), [rmask] "s"(RING - 1), [rrows] "s"(RING - 4), [basea] "s"(label_bytes), \
 	      [high] "s"(HIGH), [k80] "s"(0x80u), [room] "s"(RING - 8), [tprep] "s"(W.tprep)                 \
-	    : "v24", "v25", "v26", "v27", "v28", "v29", "s38", "s39", "s40", "s41", "s42", "s43", "vcc", "scc", "memory")
+	    : "v24", "v25", "v26", "v27", "v28", "v29", "v30", "s38", "s39", "s40", "s41", "s42", "s43", "vcc", "scc", "memory")
 
 // K: lookups per round of the assembly loop (0: the C++ loop, rounds of W.round)
 template <uint32_t RING, uint32_t K>
@@ -1016,9 +1032,13 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 		if (threadIdx.x == 0) Qd.cursor[1] = 1u;
 		return;
 	}
-	// (ring bases are multiples of the ring size: the assembly ORs a ring offset into them)
+	// The wave's ring block: RING / 4 rows of 64 dwords, row j = dword j of every lane's ring (lane l's
+	// at 4 l): a lane's ring bytes are 256 apart per dword, and a read of one byte per lane touches 64
+	// different banks wherever the lanes stand.  (With each lane's ring in one piece, lanes 8 apart
+	// shared their banks: the read cost as much as a random one, a quarter of the kernel.)
 	LDS_AS unsigned char *wbase = lds + ((label_bytes + info_bytes + 127) & ~127u) + wave * (64 * RING);
-	LDS_AS unsigned char *ring = wbase + lane * RING;
+	LDS_AS unsigned char *ring = wbase + lane * 4;
+	auto ring_at = [&](uint32_t pos) { return ring + ((pos & (RING - 4)) << 6) + (pos & 3u); }; // byte pos of the prepared range
 	DirectLog log;
 	log.open_own(Qd, blockIdx.x * waves + wave);
 
@@ -1043,7 +1063,8 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 #pragma unroll
 			for (uint32_t k = 0; k < RING / 8; k++) {
 				const u32x2 x = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
-				*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = x;
+				*(LDS_AS uint32_t *)ring_at(fill) = x.x;
+				*(LDS_AS uint32_t *)ring_at(fill + 4) = x.y;
 				fill += 8;
 			}
 		}
@@ -1052,7 +1073,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 			const uint32_t ring_a = (uint32_t)(uintptr_t)ring;
 			const uint32_t tb = (uint32_t)((size_t)wb * rows * 64 + lane * 8); // (the transposed copy is below 4 GiB)
 			unsigned long long act = __builtin_amdgcn_ballot_w64(active), req = 0;
-			u32x2 data = {0, 0};
+			uint32_t data0 = 0, data1 = 0;
 			constexpr uint32_t high = kBatchEntries * 2 - 128 * K; // a round adds at most 64 K entries
 			while (act != 0) {
 				unsigned long long act_out, req_out;
@@ -1072,7 +1093,8 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 			unsigned long long act = __builtin_amdgcn_ballot_w64(active);
 			while (act != 0) {
 				if (req) {
-					*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = data;
+					*(LDS_AS uint32_t *)ring_at(fill) = data.x;
+					*(LDS_AS uint32_t *)ring_at(fill + 4) = data.y;
 					fill += 8;
 				}
 				req = active && (fill - lend) <= RING - 8;
@@ -1081,7 +1103,7 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 				for (uint32_t it = 0; it < round; it++) {
 					bool done = false;
 					if (active) {
-						const uint32_t c = ring[cp & (RING - 1)];
+						const uint32_t c = *ring_at(cp);
 						const uint32_t t = nb + c;
 						const uint32_t x = l_lt[t] ^ c;
 						const uint32_t b = l_base[t];
