@@ -193,6 +193,10 @@ void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t 
 // After a full-evaluation scan: repairs the ranges whose entry was not the previous range's exit
 // (counts straight into out), leaves the true entries in W.entry.  changed: two words, zero on entry;
 // epoch: 1 .. 65535, a different one for every evaluation of a plan.
+void launch_fixup_and_histogram_slots(const StreamTrieDev &T, const StreamWork &W, uint32_t *exit_b, uint32_t *changed,
+                                      uint32_t epoch, const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id,
+                                      unsigned long long *out, uint32_t total_index, uint32_t *slab, uint32_t slab_blocks,
+                                      hipStream_t stream);
 void launch_fixup_stream(const StreamTrieDev &T, const uint32_t *slot_id, const StreamWork &W, uint32_t *exit_b,
                          uint32_t *changed, uint32_t epoch, unsigned long long *out, uint32_t total_index, hipStream_t stream);
 uint64_t stream_scan_capacity_batches(uint64_t prep_total, uint32_t waves_total);

@@ -900,8 +900,8 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 // scalar instructions with no loop counter and no branch, plus 18 per round for the refill, the log's
 // capacity check and the loop (the compiler's code for the same loop, kept below for TOKSCORE_ASM=0,
 // needs about 50 per lookup).
-// Conventions: exec = lanes still inside their range (ACT); v24 = the byte at cp, read at the end of
-// the previous lookup; v25-v29, s[38:43] scratch.  The block is entered and left at the start of a
+// Conventions: exec = lanes still inside their range (ACT); v24 = the byte at cp, v31 = the byte at
+// lend; v25 (slot), v27-v30 belong to the lookup whose reads are in flight; v26, v32-v34, s[38:43] scratch.  The block is entered and left at the start of a
 // round: left when no lane is active any more or when the stream batch may not take another round
 // (the C++ around it opens the next batch and comes back), with nothing in flight.
 // Timing experiments on the round loop (csrc/Makefile `exp`, tools/dbg/ab_libs.sh; never in the product
@@ -911,7 +911,7 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 #ifdef TOK_EXP_NOSTORE
 #define TOK_EXP_STORE ""
 #else
-#define TOK_EXP_STORE "global_store_short v26, %[lslot], %[sbase]\n s_bcnt1_i32_b64 s40, exec\n s_lshl1_add_u32 %[cur], s40, %[cur]\n"
+#define TOK_EXP_STORE "global_store_short v33, %[lslot], %[sbase]\n s_bcnt1_i32_b64 s40, exec\n s_lshl1_add_u32 %[cur], s40, %[cur]\n"
 #endif
 #ifdef TOK_EXP_EXTRA_RT
 #define TOK_EXP_CHAIN "ds_read_u8 v26, v24\n s_waitcnt lgkmcnt(0)\n v_and_b32 v26, 0, v26\n v_or_b32 v24, v24, v26\n"
@@ -919,9 +919,13 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 #define TOK_EXP_CHAIN ""
 #endif
 #if defined(TOK_EXP_EXTRA_RANDOM)
-#define TOK_EXP_READ "ds_read_u8 v30, v26\n" /* one more independent read at a random address */
+#define TOK_EXP_READ "ds_read_u8 v32, v26\n" /* one more independent read at a random address */
+#elif defined(TOK_EXP_EXTRA_VALU4)
+#define TOK_EXP_READ "v_mov_b32 v32, v32\n v_mov_b32 v32, v32\n v_mov_b32 v32, v32\n v_mov_b32 v32, v32\n" /* four more vector instructions */
+#elif defined(TOK_EXP_EXTRA_SALU4)
+#define TOK_EXP_READ "s_mov_b32 s40, s40\n s_mov_b32 s40, s40\n s_mov_b32 s40, s40\n s_mov_b32 s40, s40\n" /* four more scalar instructions */
 #elif defined(TOK_EXP_EXTRA_BCAST)
-#define TOK_EXP_READ "v_mov_b32 v30, 0\n ds_read_u8 v30, v30\n" /* ... at one address for all lanes */
+#define TOK_EXP_READ "v_mov_b32 v32, 0\n ds_read_u8 v32, v32\n" /* ... at one address for all lanes */
 #else
 #define TOK_EXP_READ ""
 #endif
@@ -931,6 +935,24 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	"v_and_b32 " DST ", %[rrows], " POS "\n"                                                 \
 	"v_lshl_add_u32 " DST ", " DST ", 6, %[rbase]\n"                                         \
 	"v_and_or_b32 " DST ", " POS ", 3, " DST "\n"
+#ifdef TOK_EXP_NOPRIO
+#define TOK_PRIO_HIGH ""
+#define TOK_PRIO_LOW ""
+#else
+#define TOK_PRIO_HIGH "s_setprio 2\n"
+#define TOK_PRIO_LOW "s_setprio 0\n"
+#endif
+// the reads of one lookup: the slot the byte at cp (v24) leads to from node nb, and the byte at cp + 1
+// (v30; beside the slot reads, so that no lookup waits for a byte: the next byte is v30 or v31)
+#define TOK_ISSUE_LOOKUP                                                                     \
+	"v_add_u32 v25, %[nb], v24\n"                 /* slot t = LDS address of lt[t]     */     \
+	"v_lshl_add_u32 v26, v25, 1, %[basea]\n"      /* address of base[t]                */     \
+	"ds_read_u8 v27, v25\n"                                                                   \
+	"ds_read_u16 v28, v26\n"                                                                  \
+	TOK_EXP_READ                                                                              \
+	"v_add_u32 v29, 1, %[cp]\n"                                                               \
+	TOK_RING_BYTE_ADDR("v30", "v29")                                                          \
+	"ds_read_u8 v30, v30\n"
 #define TOK_RANGES_ASM(K, HIGH)                                                              \
 	asm volatile(                                                                             \
 	    "s_mov_b64 s[38:39], exec\n"                                                          \
@@ -939,7 +961,11 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "s_mov_b32 %[cur], %[curin]\n"                                                        \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
 	    TOK_RING_BYTE_ADDR("v25", "%[cp]")                                                    \
+	    TOK_RING_BYTE_ADDR("v26", "%[lend]")                                                  \
 	    "ds_read_u8 v24, v25\n"                                                               \
+	    "ds_read_u8 v31, v26\n"                                                               \
+	    "s_waitcnt lgkmcnt(0)\n"                                                              \
+	    TOK_ISSUE_LOOKUP                               /* the first lookup's reads          */ \
 	    ".Lround%=:\n"                                /* refill, then a round of K lookups */ \
 	    "s_cmp_eq_u64 %[act], 0\n"                                                            \
 	    "s_cbranch_scc1 .Lout%=\n"                                                            \
@@ -947,30 +973,23 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "s_cbranch_scc1 .Lout%=\n"                                                            \
 	    "s_waitcnt vmcnt(4)\n"                        /* (in issue order: the piece came before the round's >= 4 stores) */ \
 	    "s_mov_b64 exec, %[req]\n"                    /* the piece asked for a round ago   */ \
-	    "v_and_b32 v25, %[rmask], %[fill]\n"          /* (a multiple of 8: dword rows 2 j, 2 j + 1) */ \
-	    "v_lshl_add_u32 v25, v25, 6, %[rbase]\n"                                              \
-	    "ds_write2st64_b32 v25, %[d0], %[d1] offset1:1\n"                                     \
+	    "v_and_b32 v34, %[rmask], %[fill]\n"          /* (a multiple of 8: dword rows 2 j, 2 j + 1) */ \
+	    "v_lshl_add_u32 v34, v34, 6, %[rbase]\n"                                              \
+	    "ds_write2st64_b32 v34, %[d0], %[d1] offset1:1\n"                                     \
 	    "v_add_u32 %[fill], 8, %[fill]\n"                                                     \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
-	    "v_sub_u32 v25, %[fill], %[lend]\n"                                                   \
-	    "v_cmp_ge_u32 vcc, %[room], v25\n"            /* room for another piece            */ \
+	    "v_sub_u32 v34, %[fill], %[lend]\n"                                                   \
+	    "v_cmp_ge_u32 vcc, %[room], v34\n"            /* room for another piece            */ \
 	    "s_mov_b64 %[req], vcc\n"                                                             \
 	    "s_mov_b64 exec, vcc\n"                                                               \
-	    "v_lshl_add_u32 v25, %[fill], 6, %[tb]\n"                                             \
+	    "v_lshl_add_u32 v34, %[fill], 6, %[tb]\n"                                             \
 	    "s_waitcnt lgkmcnt(0)\n"                      /* (d0, d1 are free again)           */ \
-	    "global_load_dword %[d0], v25, %[tprep]\n"                                            \
-	    "global_load_dword %[d1], v25, %[tprep] offset:4\n"                                   \
+	    "global_load_dword %[d0], v34, %[tprep]\n"                                            \
+	    "global_load_dword %[d1], v34, %[tprep] offset:4\n"                                   \
 	    "s_mov_b64 exec, %[act]\n"                                                            \
 	    ".rept " #K "\n"                                                                      \
-	    "s_waitcnt lgkmcnt(0)\n"                                                              \
-	    "s_setprio 2\n"                               /* the dependent part of a lookup goes before other waves' logging */ \
+	    TOK_PRIO_HIGH                                  /* the dependent part of a lookup goes before other waves' logging */ \
 	    TOK_EXP_CHAIN                                                                         \
-	    "v_add_u32 v25, %[nb], v24\n"                 /* slot t = LDS address of lt[t]     */ \
-	    "v_lshl_add_u32 v26, v25, 1, %[basea]\n"      /* address of base[t]                */ \
-	    "ds_read_u8 v27, v25\n"                                                               \
-	    "ds_read_u16 v28, v26\n"                                                              \
-	    TOK_EXP_READ                                                                          \
-	    "v_add_u32 v29, 1, %[cp]\n"                                                           \
 	    "s_waitcnt lgkmcnt(0)\n"                                                              \
 	    "v_xor_b32 v27, v27, v24\n"                   /* 0x80 hit on a token end, 0 hit    */ \
 	    "v_cmp_ne_u32 s[42:43], 0, v28\n"             /* the slot has children             */ \
@@ -979,16 +998,17 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    "v_cmp_eq_u32 vcc, 0, v26\n"                  /* hit                               */ \
 	    "v_cndmask_b32 %[lend], %[lend], v29, s[40:41]\n" /* (gfx950: two states between a VALU's mask and the VALU reading it) */ \
 	    "v_cndmask_b32 %[lslot], %[lslot], v25, s[40:41]\n"                                   \
+	    "v_cndmask_b32 v31, v31, v30, s[40:41]\n"     /* v31 = the byte at lend, kept in a register */ \
 	    "s_and_b64 s[40:41], vcc, s[42:43]\n"         /* the token goes on                 */ \
 	    "v_cndmask_b32 %[cp], %[lend], v29, s[40:41]\n" /* ... or the next token starts at lend */ \
 	    "v_cndmask_b32 %[nb], 0, v28, s[40:41]\n"     /* token complete: 0 = the root again */ \
-	    TOK_RING_BYTE_ADDR("v25", "%[cp]")                                                    \
-	    "ds_read_u8 v24, v25\n"                                                               \
-	    "s_setprio 0\n"                                                                       \
+	    "v_cndmask_b32 v24, v31, v30, s[40:41]\n"     /* the byte at the new cp: no read to wait for */ \
+	    TOK_ISSUE_LOOKUP                               /* the next lookup's reads, under way while this one's token is logged */ \
+	    TOK_PRIO_LOW                                                                          \
 	    "s_andn2_b64 exec, exec, s[40:41]\n"          /* lanes whose token is complete     */ \
-	    "v_mbcnt_lo_u32_b32 v26, exec_lo, 0\n"                                                \
-	    "v_mbcnt_hi_u32_b32 v26, exec_hi, v26\n"      /* rank among them                   */ \
-	    "v_lshl_add_u32 v26, v26, 1, %[cur]\n"        /* byte offset in the wave's stream batch */ \
+	    "v_mbcnt_lo_u32_b32 v33, exec_lo, 0\n"                                                \
+	    "v_mbcnt_hi_u32_b32 v33, exec_hi, v33\n"      /* rank among them                   */ \
+	    "v_lshl_add_u32 v33, v33, 1, %[cur]\n"        /* byte offset in the wave's stream batch */ \
 	    TOK_EXP_STORE                                                                         \
 	    "v_cmp_ge_u32 vcc, %[cp], %[hi]\n"            /* range done                        */ \
 	    "s_andn2_b64 %[act], %[act], vcc\n"                                                   \
@@ -1003,7 +1023,7 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	    : [actin] "s"(uni64(act)), [reqin] "s"(uni64(req)), [curin] "s"(uni32(log.cur)), [sbase] "s"(uni64((unsigned long long)(uintptr_t)log.base)), \
 	      [hi] "v"(end), [rbase] "v"(ring_a), [tb] "v"(tb), [rmask] "s"(RING - 1), [rrows] "s"(RING - 4), [basea] "s"(label_bytes), \
 	      [high] "s"(HIGH), [k80] "s"(0x80u), [room] "s"(RING - 8), [tprep] "s"(W.tprep)                 \
-	    : "v24", "v25", "v26", "v27", "v28", "v29", "v30", "s38", "s39", "s40", "s41", "s42", "s43", "vcc", "scc", "memory")
+	    : "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "s38", "s39", "s40", "s41", "s42", "s43", "vcc", "scc", "memory")
 
 // K: lookups per round of the assembly loop (0: the C++ loop, rounds of W.round)
 template <uint32_t RING, uint32_t K>
@@ -1281,6 +1301,7 @@ struct FixDev {
 	uint32_t epoch;    // 1 .. 65535, another one every evaluation: exit_b[g] counts only when tagged with it
 	unsigned long long *out;
 	uint32_t total_index;
+	uint32_t blocks; // workgroups that take part (the first ones of the launch)
 };
 
 // one token of the chain at pos: its length and the slot it ends on (the root row is dense and
@@ -1328,11 +1349,15 @@ __device__ bool dual_walk_image(const FixDev &F, uint32_t end, uint32_t pa, uint
 
 __device__ void fixup_ordered_pass(const FixDev &F);
 
-__global__ void __launch_bounds__(256) fixup_parallel_stream_kernel(FixDev F) {
+// The whole fix-up, for the workgroups blockIdx.x < F.blocks of a launch (every thread of them
+// reaches every barrier).  A kernel of its own (fixup_parallel_stream_kernel) or the opening of
+// hist_slots_kernel: with an unchanged vocabulary it only compares, and a launch for that costs
+// more than the comparing (7 us of a 125 us evaluation).
+__device__ void fixup_stream_body(const FixDev &F) {
 	__shared__ uint32_t s_last, s_wrote;
 	if (threadIdx.x == 0) s_wrote = 0;
 	__syncthreads();
-	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < F.nranges; g += gridDim.x * blockDim.x) {
+	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < F.nranges; g += F.blocks * blockDim.x) {
 		uint32_t ex = F.exit_a[g];
 		(void)ex;
 		if (g > 0) {
@@ -1360,12 +1385,14 @@ __global__ void __launch_bounds__(256) fixup_parallel_stream_kernel(FixDev F) {
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		if (s_wrote) __threadfence();
-		s_last = atomicAdd(&F.changed[1], 1u) == gridDim.x - 1 ? 1u : 0u;
+		s_last = atomicAdd(&F.changed[1], 1u) == F.blocks - 1 ? 1u : 0u;
 	}
 	__syncthreads();
 	if (!s_last) return;
 	fixup_ordered_pass(F);
 }
+
+__global__ void __launch_bounds__(256) fixup_parallel_stream_kernel(FixDev F) { fixup_stream_body(F); }
 
 // ONE workgroup; every thread reaches every barrier.  Does nothing unless a repair moved an exit.
 // exit of range g after the repairs so far: exit_b where this evaluation wrote one (published by
@@ -1427,10 +1454,13 @@ __host__ __device__ __forceinline__ uint32_t slab_row_stride(uint32_t nslots) { 
 template <bool ONE_RANGE>
 __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t nslots, uint32_t range_slots, int16_t *slab,
                                                           uint32_t flip, const uint32_t *slot_id, unsigned long long *out,
-                                                          uint32_t total_index) {
+                                                          uint32_t total_index, FixDev F) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char hist_smem[];
 	uint32_t *bins = reinterpret_cast<uint32_t *>(hist_smem);
 	__shared__ int s_total;
+	// a full evaluation's fix-up rides along (F.blocks != 0): it and the histogram only meet in `out`,
+	// which both add to with atomics
+	if (F.blocks != 0 && blockIdx.y == 0 && blockIdx.x < F.blocks) fixup_stream_body(F);
 	const uint32_t lo = ONE_RANGE ? 0u : blockIdx.y * range_slots;
 	const uint32_t hi = lo + range_slots < nslots ? lo + range_slots : nslots;
 	const uint32_t width = hi - lo;
@@ -1771,8 +1801,9 @@ void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const Stre
 	else go(&walk_toggles_kernel<128>);
 }
 
-void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
-                            uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip) {
+namespace {
+void histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
+                     uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip, FixDev F) {
 	constexpr uint32_t kMaxRange = 40000;
 	const uint32_t ranges = (nslots + kMaxRange - 1) / kMaxRange;
 	const uint32_t range = (nslots + ranges - 1) / ranges;
@@ -1781,20 +1812,41 @@ void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t 
 	auto go = [&](auto kernel) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		hipLaunchKernelGGL(kernel, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, nslots, range, rows, flip ? 1u : 0u,
-		                   slot_id, out, total_index);
+		                   slot_id, out, total_index, F);
 	};
+	if (F.blocks > slab_blocks) F.blocks = slab_blocks;
 	if (ranges == 1) go(&hist_slots_kernel<true>);
 	else go(&hist_slots_kernel<false>);
 	hipLaunchKernelGGL(slab_reduce_map_kernel, dim3((nslots + 127) / 128), dim3(64 * kMapReduceGroups), 0, stream, rows,
 	                   slab_blocks, nslots, slot_id, out, total_index);
 }
+} // namespace
+
+void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
+                            uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip) {
+	histogram_slots(Q, nslots, slot_id, out, total_index, slab, slab_blocks, stream, flip, FixDev{});
+}
+
+// A full evaluation's last two steps in one launch: the fix-up of the ranges (launch_fixup_stream) by
+// the first workgroups of the histogram kernel, then the histogram and its reduction.
+void launch_fixup_and_histogram_slots(const StreamTrieDev &T, const StreamWork &W, uint32_t *exit_b, uint32_t *changed,
+                                      uint32_t epoch, const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id,
+                                      unsigned long long *out, uint32_t total_index, uint32_t *slab, uint32_t slab_blocks,
+                                      hipStream_t stream) {
+	FixDev F{};
+	if (W.nranges >= 2) {
+		F = FixDev{T, slot_id, W.prep, W.prep_total, W.range_bytes, W.nranges, W.entry, W.exit_a, exit_b, changed, epoch, out, total_index,
+		           std::min<uint32_t>((W.nranges + 1023) / 1024, 64)};
+	}
+	histogram_slots(Q, nslots, slot_id, out, total_index, slab, slab_blocks, stream, false, F);
+}
 
 void launch_fixup_stream(const StreamTrieDev &T, const uint32_t *slot_id, const StreamWork &W, uint32_t *exit_b,
                          uint32_t *changed, uint32_t epoch, unsigned long long *out, uint32_t total_index, hipStream_t stream) {
 	if (W.nranges < 2) return;
-	FixDev F{T, slot_id, W.prep, W.prep_total, W.range_bytes, W.nranges, W.entry, W.exit_a, exit_b, changed, epoch, out, total_index};
 	// (few workgroups: each ends with an atomic on one word, which takes about 10 ns chip-wide)
 	const uint32_t blocks = std::min<uint32_t>((W.nranges + 255) / 256, 64);
+	FixDev F{T, slot_id, W.prep, W.prep_total, W.range_bytes, W.nranges, W.entry, W.exit_a, exit_b, changed, epoch, out, total_index, blocks};
 	hipLaunchKernelGGL(fixup_parallel_stream_kernel, dim3(blocks), dim3(256), 0, stream, F);
 }
 

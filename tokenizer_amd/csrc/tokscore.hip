@@ -861,10 +861,8 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		HIP_TRY(c, mark(2));
 		// ranges whose entry was not the previous range's exit (none while the vocabulary stays as it is)
 		c->fix_epoch = c->fix_epoch % 65535u + 1u;
-		launch_fixup_stream(stream_trie_dev(c), c->d_slot_id, W, c->d_range_state + 2 * (size_t)c->nranges, c->d_cursor + 2, c->fix_epoch, d_out,
-		                    (uint32_t)c->V + 3, s);
-		launch_histogram_slots(Q, (uint32_t)c->simg.lt.size(), c->d_slot_id, d_out, (uint32_t)c->V + 3, c->d_slab,
-		                       c->slab_blocks, s);
+		launch_fixup_and_histogram_slots(stream_trie_dev(c), W, c->d_range_state + 2 * (size_t)c->nranges, c->d_cursor + 2, c->fix_epoch, Q,
+		                                 (uint32_t)c->simg.lt.size(), c->d_slot_id, d_out, (uint32_t)c->V + 3, c->d_slab, c->slab_blocks, s);
 	} else if (c->scan_path == 1) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s);
