@@ -480,6 +480,61 @@ def test_sampled_timing_marks_every_nth_evaluation_and_changes_no_result(path):
 
 
 @pytest.mark.gpu
+def test_full_evaluations_between_other_users_of_the_stream_state():
+    """A full evaluation over ranges that follows another one has no prepare launch (the scan clears
+    the output vector, the previous reduction left the cursor words ready); anything else that uses
+    the token stream in between -- occurrence counting, toggles with incremental re-scores, batched
+    moves -- must put the next evaluation back on the prepared path.  Two output buffers in turn:
+    each holds a whole result whatever it held before."""
+    corpus, off = synth.wiki_like(1_500_000, seed=33)
+    tokens = synth.build_vocab(corpus[:400_000], 4000)
+    V = len(tokens)
+    ora = O.OracleVocab(*synth.pack_vocab(tokens))
+    exp = ora.score(corpus, off, threads=8)
+    s, old = _scorer({"TOKSCORE_SCAN": "stream"})
+    a = b = None
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        a, b = _DeviceBuffer((V + 5) * 8), _DeviceBuffer((V + 5) * 8)
+
+        def check(buf):
+            assert s.async_status() is False  # (waits for the context's stream)
+            got = buf.to_host()
+            assert np.array_equal(got[:V + 3], exp[0]) and int(got[V + 3]) == exp[1] and int(got[V + 4]) == exp[2]
+
+        for buf in (a, b, a, a, b):
+            s.score_async(buf.ptr.value)
+            check(buf)
+        counts, _ = s.count_occurrences(6)
+        assert np.array_equal(np.asarray(counts), np.asarray(ora.count_occurrences(corpus, off, 6)[0]))
+        for buf in (b, a):
+            s.score_async(buf.ptr.value)
+            check(buf)
+        pick = [i for i, t in enumerate(tokens) if len(t) >= 3][:3]
+        for i in pick:  # off and on again through the incremental path, a full evaluation after each
+            s.toggle(i, False)
+            s.score(incremental=True)
+            s.toggle(i, True)
+            r = s.score(incremental=True)
+            assert r[1] == exp[1]
+            s.score_async(a.ptr.value)
+            check(a)
+        s.score_toggles(pick, [False] * len(pick))
+        for buf in (a, b):
+            s.score_async(buf.ptr.value)
+            check(buf)
+        r = s.score()
+        assert np.array_equal(r[0], exp[0]) and r[1] == exp[1]
+    finally:
+        _restore(old)
+        s.close()
+        for buf in (a, b):
+            if buf:
+                buf.free()
+
+
+@pytest.mark.gpu
 def test_bench_exchange_runs_over_rccl_on_one_rank():
     """bench.py's N > 1 exchange (score_async, then all_reduce of the u64 vector on the same stream,
     barrier, max over ranks) executed with RCCL on the hardware that is there: a communicator of one

@@ -185,18 +185,28 @@ void launch_local_toggles(const StreamTrieDev &T, const StreamWork &W, uint32_t 
 bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, StreamScanPlan *plan);
 void launch_transpose_ranges(const uint8_t *prep, uint64_t prep_readable, uint32_t range_bytes, uint32_t halo, uint32_t nblocks,
                              uint8_t *tprep, hipStream_t stream);
+// init (optional): the output vector the evaluation will add to, cleared and preset by the scan's
+// own workgroups before they start (what prepare_kernel does in a launch of its own otherwise)
+struct OutInit {
+	unsigned long long *out = nullptr; // V + 5 words: counts | total_tokens | total_bytes
+	uint32_t V = 0;
+	unsigned long long D = 0, total_bytes = 0;
+};
 void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
-                        hipStream_t stream);
+                        hipStream_t stream, const OutInit &init = OutInit{});
 // out[slot_id[s]] += occurrences of slot s in the stream, out[total_index] += entries on counted slots
 void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
                             uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip = false);
 // After a full-evaluation scan: repairs the ranges whose entry was not the previous range's exit
 // (counts straight into out), leaves the true entries in W.entry.  changed: two words, zero on entry;
 // epoch: 1 .. 65535, a different one for every evaluation of a plan.
+// next_first_batches != 0: the reduction leaves Q.cursor as prepare_kernel would set it for the next
+// full evaluation (batches handed out = next_first_batches, the fix-up's two words zero; the
+// overflow word is left alone), so that evaluation needs no prepare launch
 void launch_fixup_and_histogram_slots(const StreamTrieDev &T, const StreamWork &W, uint32_t *exit_b, uint32_t *changed,
                                       uint32_t epoch, const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id,
                                       unsigned long long *out, uint32_t total_index, uint32_t *slab, uint32_t slab_blocks,
-                                      hipStream_t stream);
+                                      hipStream_t stream, uint32_t next_first_batches = 0);
 void launch_fixup_stream(const StreamTrieDev &T, const uint32_t *slot_id, const StreamWork &W, uint32_t *exit_b,
                          uint32_t *changed, uint32_t epoch, unsigned long long *out, uint32_t total_index, hipStream_t stream);
 uint64_t stream_scan_capacity_batches(uint64_t prep_total, uint32_t waves_total);

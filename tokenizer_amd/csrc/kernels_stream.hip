@@ -1027,9 +1027,12 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 
 // K: lookups per round of the assembly loop (0: the C++ loop, rounds of W.round)
 template <uint32_t RING, uint32_t K>
-__global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, StreamWork W, StreamDev Qd) {
+__global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, StreamWork W, StreamDev Qd, OutInit I) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char ranges_smem[];
 	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)ranges_smem;
+	if (I.out) // (nothing else touches the output vector before this kernel has ended)
+		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < I.V + 5; i += gridDim.x * blockDim.x)
+			I.out[i] = i < 2 ? I.D : (i == I.V + 4 ? I.total_bytes : 0ull);
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = uni32(threadIdx.x >> 6);
 	const uint32_t waves = blockDim.x >> 6;
@@ -1565,8 +1568,10 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 constexpr uint32_t kMapReduceGroups = 16;
 __global__ void __launch_bounds__(1024) slab_reduce_map_kernel(const int16_t *slab, uint32_t rows, uint32_t nslots,
                                                                const uint32_t *slot_id, unsigned long long *out,
-                                                               uint32_t total_index) {
+                                                               uint32_t total_index, uint32_t *cursor, uint32_t next_first_batches) {
 	__shared__ int part[kMapReduceGroups][64][2];
+	// (the histogram has read cursor[0], the fix-up is done with its two words: ready for the next evaluation)
+	if (next_first_batches != 0 && blockIdx.x == 0 && threadIdx.x == 0) cursor[0] = next_first_batches, cursor[2] = 0u, cursor[3] = 0u;
 	const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
 	const uint32_t s = blockIdx.x * 128 + lane * 2;
 	const size_t stride = slab_row_stride(nslots) / 2; // in 32-bit words
@@ -1675,11 +1680,11 @@ bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, Strea
 }
 
 void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
-                        hipStream_t stream) {
+                        hipStream_t stream, const OutInit &init) {
 	auto go = [&](auto kernel) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                          (int)plan.lds_bytes);
-		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, T, W, Q);
+		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, T, W, Q, init);
 	};
 	static const bool use_asm = [] {
 		const char *e = getenv("TOKSCORE_ASM");
@@ -1803,7 +1808,8 @@ void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const Stre
 
 namespace {
 void histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
-                     uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip, FixDev F) {
+                     uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip, FixDev F,
+                     uint32_t next_first_batches = 0) {
 	constexpr uint32_t kMaxRange = 40000;
 	const uint32_t ranges = (nslots + kMaxRange - 1) / kMaxRange;
 	const uint32_t range = (nslots + ranges - 1) / ranges;
@@ -1818,7 +1824,7 @@ void histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_i
 	if (ranges == 1) go(&hist_slots_kernel<true>);
 	else go(&hist_slots_kernel<false>);
 	hipLaunchKernelGGL(slab_reduce_map_kernel, dim3((nslots + 127) / 128), dim3(64 * kMapReduceGroups), 0, stream, rows,
-	                   slab_blocks, nslots, slot_id, out, total_index);
+	                   slab_blocks, nslots, slot_id, out, total_index, Q.cursor, next_first_batches);
 }
 } // namespace
 
@@ -1832,13 +1838,13 @@ void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t 
 void launch_fixup_and_histogram_slots(const StreamTrieDev &T, const StreamWork &W, uint32_t *exit_b, uint32_t *changed,
                                       uint32_t epoch, const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id,
                                       unsigned long long *out, uint32_t total_index, uint32_t *slab, uint32_t slab_blocks,
-                                      hipStream_t stream) {
+                                      hipStream_t stream, uint32_t next_first_batches) {
 	FixDev F{};
 	if (W.nranges >= 2) {
 		F = FixDev{T, slot_id, W.prep, W.prep_total, W.range_bytes, W.nranges, W.entry, W.exit_a, exit_b, changed, epoch, out, total_index,
 		           std::min<uint32_t>((W.nranges + 1023) / 1024, 64)};
 	}
-	histogram_slots(Q, nslots, slot_id, out, total_index, slab, slab_blocks, stream, false, F);
+	histogram_slots(Q, nslots, slot_id, out, total_index, slab, slab_blocks, stream, false, F, next_first_batches);
 }
 
 void launch_fixup_stream(const StreamTrieDev &T, const uint32_t *slot_id, const StreamWork &W, uint32_t *exit_b,

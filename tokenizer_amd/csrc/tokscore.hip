@@ -117,6 +117,10 @@ struct tokscore_ctx {
 	// d_out holds the result of the last synchronous evaluation of the resident corpus under
 	// the device trie's state (what an incremental re-score starts from)
 	bool state_valid = false;
+	// the last use of the token stream's cursor words was a full evaluation over ranges, whose
+	// reduction left them as the next one needs them (stream_ready = its number of waves): that
+	// evaluation then has no prepare launch.  Every other user of the words clears this.
+	uint32_t stream_ready = 0;
 	uint32_t rescored_chunks = 0xFFFFFFFFu; // by the last incremental re-score (UINT32_MAX: full evaluation)
 
 	// corpus
@@ -665,6 +669,7 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_begin, c->h_chunk_begin.size() * sizeof(uint64_t)));
 	HIP_TRY(c, hipMemcpy(c->d_chunk_begin, c->h_chunk_begin.data(), c->h_chunk_begin.size() * sizeof(uint64_t),
 	                     hipMemcpyHostToDevice));
+	c->stream_ready = 0;
 	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, kCursorWords * sizeof(uint32_t)));
 	HIP_TRY(c, hipMalloc((void **)&c->d_sel, ((size_t)(c->nchunks + 31) / 32 + 1) * sizeof(uint32_t)));
 	HIP_TRY(c, hipMalloc((void **)&c->d_sel_list, ((size_t)c->nchunks + 1) * sizeof(uint32_t)));
@@ -762,6 +767,7 @@ int ensure_plan(tokscore_ctx *c) {
 		HIP_TRY(c, hipMalloc((void **)&c->d_chunk_first_doc, first.size() * sizeof(uint64_t)));
 		HIP_TRY(c, hipMemcpy(c->d_chunk_first_doc, first.data(), first.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
 	}
+	c->stream_ready = 0;
 	HIP_TRY(c, hipMalloc((void **)&c->d_cursor, kCursorWords * sizeof(uint32_t)));
 	HIP_TRY(c, hipMalloc((void **)&c->d_sel, ((size_t)(c->nchunks + 31) / 32 + 1) * sizeof(uint32_t)));
 	HIP_TRY(c, hipMalloc((void **)&c->d_sel_list, ((size_t)c->nchunks + 1) * sizeof(uint32_t)));
@@ -853,18 +859,27 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	auto mark = [&](int k) -> hipError_t { return ev && (!scan_only || k == 1 || k == 2) ? hipEventRecord(ev[k], s) : hipSuccess; };
 	if (c->scan_path == 2) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
-		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s, c->d_tprep ? c->rplan.blocks * c->rplan.waves_per_block : 0u);
+		const uint32_t first_batches = c->d_tprep ? c->rplan.blocks * c->rplan.waves_per_block : 0u;
+		const bool ready = first_batches != 0 && c->stream_ready == first_batches;
+		c->stream_ready = 0;
+		if (!ready) launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s, first_batches);
 		HIP_TRY(c, mark(1));
 		const StreamWork W = stream_work(c, false);
-		if (c->d_tprep) launch_scan_ranges(stream_trie_dev(c), W, Q, c->rplan, s);
-		else launch_scan_stream(stream_trie_dev(c), W, Q, c->splan, s);
+		if (c->d_tprep) {
+			OutInit init;
+			if (ready) init = OutInit{d_out, (uint32_t)c->V, c->D, c->total};
+			launch_scan_ranges(stream_trie_dev(c), W, Q, c->rplan, s, init);
+		} else launch_scan_stream(stream_trie_dev(c), W, Q, c->splan, s);
 		HIP_TRY(c, mark(2));
 		// ranges whose entry was not the previous range's exit (none while the vocabulary stays as it is)
 		c->fix_epoch = c->fix_epoch % 65535u + 1u;
 		launch_fixup_and_histogram_slots(stream_trie_dev(c), W, c->d_range_state + 2 * (size_t)c->nranges, c->d_cursor + 2, c->fix_epoch, Q,
-		                                 (uint32_t)c->simg.lt.size(), c->d_slot_id, d_out, (uint32_t)c->V + 3, c->d_slab, c->slab_blocks, s);
+		                                 (uint32_t)c->simg.lt.size(), c->d_slot_id, d_out, (uint32_t)c->V + 3, c->d_slab, c->slab_blocks, s,
+		                                 first_batches);
+		c->stream_ready = first_batches;
 	} else if (c->scan_path == 1) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
+		c->stream_ready = 0;
 		launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s);
 		HIP_TRY(c, mark(1));
 		launch_scan_tile(T, C, S, Q, c->tile, c->d_chunk_first_doc, c->packed.max_len, s);
@@ -1098,6 +1113,7 @@ int count_on_stream_image(tokscore_ctx *c, uint32_t max_cp, uint64_t *counts, ui
 	}
 	StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 	HIP_TRY(c, hipMemsetAsync(c->d_slot_ends, 0, ((size_t)nslots + 2) * sizeof(unsigned long long), s));
+	c->stream_ready = 0;
 	launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s, c->rplan.blocks * c->rplan.waves_per_block);
 	StreamWork W = stream_work(c, false);
 	W.tprep = c->d_tprep_raw;
@@ -1526,6 +1542,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		HIP_TRY(c, mark(1));
 		// one partial pass: the selected chunks scanned under the device trie as it is now
 		auto partial_pass = [&](bool flip) {
+			c->stream_ready = 0;
 			launch_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Q, s);
 			if (c->scan_path == 2) {
 				StreamWork Wp = stream_work(c, !streams_listed);
