@@ -915,16 +915,23 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	return TOKSCORE_OK;
 }
 
-// Occurrence index for incremental re-scores (kernels_generic.hip: index_all_kernel).  Skipped
-// when it would take more than TOKSCORE_INDEX_MB (default 2048) of HBM; the re-score then
-// searches the corpus for each toggled string instead.
+// Occurrence index for incremental re-scores and batched moves (kernels_generic.hip:
+// index_all_kernel).  Skipped when it would take more than TOKSCORE_INDEX_MB of HBM (default 32768:
+// config 2's per-GPU share, 2.5 GB at V = 32 k, needs 2.4 GB, and without it a batch of moves falls
+// back to a re-score per move -- 147 instead of tens of thousands of moves/s) or more than half of
+// what is free on the device; the re-score then searches the corpus for each toggled string instead.
 void build_index(tokscore_ctx *c) {
 	c->index_state = -1;
 	std::vector<int32_t> slot_row;
 	const uint32_t rows = c->trie.StringRows(c->packed.slots.size(), &slot_row, &c->tok_row);
 	const uint32_t wpr = (c->nchunks + 31) / 32;
 	const uint64_t bytes = (uint64_t)rows * wpr * sizeof(uint32_t);
-	if (rows == 0 || bytes > env_u64("TOKSCORE_INDEX_MB", 2048) * (1ull << 20)) return;
+	size_t free_b = 0, total_b = 0;
+	if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+		(void)hipGetLastError();
+		free_b = 0;
+	}
+	if (rows == 0 || bytes > env_u64("TOKSCORE_INDEX_MB", 32768) * (1ull << 20) || bytes > free_b / 2) return;
 	int32_t *d_slot_row = nullptr;
 	uint32_t *d_counts = nullptr;
 	bool ok = hipMalloc((void **)&c->d_index, bytes) == hipSuccess &&
