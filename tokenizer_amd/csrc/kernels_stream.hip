@@ -1152,6 +1152,108 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 	log.close(Qd, lane);
 }
 
+// count_ends_kernel's round loop in gfx950 assembly: scan_ranges_kernel's (TOK_RANGES_ASM: same ring
+// rows, same refill, same pipelining -- a lookup's reads are issued before the previous one's entry
+// is logged, and no lookup waits for a byte: the next byte is the one at cp + 1 (v30) or the one at
+// p + 1 (v31, kept from the window's first lookup)) with the rules of a window walk instead of a
+// greedy chain.  p = window start, cp = byte looked up, ncp = code points matched, last = deepest slot hit.
+// Masks: s[40:41] lead (the byte starts a code point or is a separator), s[42:43] first (cp == p),
+// s[44:45] separator, s[46:47] max_cp code points matched, s[48:49] the slot has children,
+// s[50:51] skip (no window starts here), s[52:53] stop / skip or stop, vcc label match -> hit -> goes on.
+#define TOK_COUNT_ASM(K, HIGH)                                                               \
+	asm volatile(                                                                             \
+	    "s_mov_b64 s[38:39], exec\n"                                                          \
+	    "s_mov_b64 %[act], %[actin]\n"                                                        \
+	    "s_mov_b64 %[req], %[reqin]\n"                                                        \
+	    "s_mov_b32 %[cur], %[curin]\n"                                                        \
+	    "s_mov_b32 %[np], 0\n"                                                                \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    "v_add_u32 v36, 1, %[p]\n"                                                            \
+	    TOK_RING_BYTE_ADDR("v25", "%[cp]")                                                    \
+	    TOK_RING_BYTE_ADDR("v26", "v36")                                                      \
+	    "ds_read_u8 v24, v25\n"                                                               \
+	    "ds_read_u8 v31, v26\n"                                                               \
+	    "s_waitcnt lgkmcnt(0)\n"                                                              \
+	    TOK_ISSUE_LOOKUP                                                                      \
+	    ".Lround%=:\n"                                                                        \
+	    "s_cmp_eq_u64 %[act], 0\n"                                                            \
+	    "s_cbranch_scc1 .Lout%=\n"                                                            \
+	    "s_cmp_gt_u32 %[cur], %[high]\n"                                                      \
+	    "s_cbranch_scc1 .Lout%=\n"                                                            \
+	    "s_waitcnt vmcnt(4)\n"                        /* (in issue order: the piece came before the round's >= 4 stores) */ \
+	    "s_mov_b64 exec, %[req]\n"                                                            \
+	    "v_and_b32 v34, %[rmask], %[fill]\n"                                                  \
+	    "v_lshl_add_u32 v34, v34, 6, %[rbase]\n"                                              \
+	    "ds_write2st64_b32 v34, %[d0], %[d1] offset1:1\n"                                     \
+	    "v_add_u32 %[fill], 8, %[fill]\n"                                                     \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    "v_sub_u32 v34, %[fill], %[p]\n"                                                      \
+	    "v_cmp_ge_u32 vcc, %[room], v34\n"            /* room for another piece (nothing before p is read again) */ \
+	    "s_mov_b64 %[req], vcc\n"                                                             \
+	    "s_mov_b64 exec, vcc\n"                                                               \
+	    "v_lshl_add_u32 v34, %[fill], 6, %[tb]\n"                                             \
+	    "s_waitcnt lgkmcnt(0)\n"                                                              \
+	    "global_load_dword %[d0], v34, %[tprep]\n"                                            \
+	    "global_load_dword %[d1], v34, %[tprep] offset:4\n"                                   \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    ".rept " #K "\n"                                                                      \
+	    TOK_PRIO_HIGH                                                                         \
+	    "s_waitcnt lgkmcnt(0)\n"                                                              \
+	    "v_xor_b32 v27, v27, v24\n"                                                           \
+	    "v_cmp_gt_u32 s[40:41], %[fcont], v24\n"      /* lead                              */ \
+	    "v_cmp_eq_u32 s[42:43], %[cp], %[p]\n"        /* first                             */ \
+	    "v_cmp_eq_u32 s[44:45], 0, v24\n"             /* separator                         */ \
+	    "v_cmp_eq_u32 s[46:47], %[maxcp], %[ncp]\n"   /* the window is full                */ \
+	    "v_and_b32 v26, 0x7f, v27\n"                                                          \
+	    "v_cmp_eq_u32 vcc, 0, v26\n"                  /* the label matches                 */ \
+	    "v_cmp_ne_u32 s[48:49], 0, v28\n"             /* the slot has children             */ \
+	    "s_orn2_b64 s[50:51], s[44:45], s[40:41]\n"                                           \
+	    "s_and_b64 s[50:51], s[50:51], s[42:43]\n"    /* skip = first and (separator or not lead) */ \
+	    "s_or_b64 s[52:53], s[44:45], s[46:47]\n"                                             \
+	    "s_and_b64 s[52:53], s[52:53], s[40:41]\n"                                            \
+	    "s_andn2_b64 s[52:53], s[52:53], s[42:43]\n"  /* stop = not first and lead and (separator or full) */ \
+	    "s_or_b64 s[52:53], s[52:53], s[50:51]\n"                                             \
+	    "s_andn2_b64 vcc, vcc, s[52:53]\n"            /* hit                               */ \
+	    "v_cndmask_b32 v31, v31, v30, s[42:43]\n"     /* v31 = the byte at p + 1           */ \
+	    "v_cndmask_b32_e32 %[last], %[last], v25, vcc\n"                                      \
+	    "s_and_b64 s[46:47], vcc, s[40:41]\n"         /* hit on a code point's first byte  */ \
+	    "s_and_b64 vcc, vcc, s[48:49]\n"              /* the walk goes on                  */ \
+	    "v_addc_co_u32 v26, s[54:55], 0, %[ncp], s[46:47]\n"                                  \
+	    "v_add_u32 v36, 1, %[p]\n"                                                            \
+	    "v_cndmask_b32_e32 %[ncp], 0, v26, vcc\n"                                             \
+	    "v_cndmask_b32_e32 %[nb], 0, v28, vcc\n"                                              \
+	    "v_cndmask_b32_e32 v24, v31, v30, vcc\n"      /* the next byte looked up           */ \
+	    "v_cndmask_b32_e32 %[p], v36, %[p], vcc\n"    /* the window ends: the next one starts one byte on */ \
+	    "v_cndmask_b32_e32 %[cp], %[p], v29, vcc\n"                                           \
+	    TOK_ISSUE_LOOKUP                                                                      \
+	    TOK_PRIO_LOW                                                                          \
+	    "s_andn2_b64 exec, exec, vcc\n"               /* lanes whose window (or skipped byte) is done */ \
+	    "s_mov_b64 s[56:57], exec\n"                                                          \
+	    "s_andn2_b64 exec, exec, s[50:51]\n"          /* ... and has an entry to log       */ \
+	    "v_mbcnt_lo_u32_b32 v33, exec_lo, 0\n"                                                \
+	    "v_mbcnt_hi_u32_b32 v33, exec_hi, v33\n"                                              \
+	    "v_lshl_add_u32 v33, v33, 1, %[cur]\n"                                                \
+	    "global_store_short v33, %[last], %[sbase]\n"                                         \
+	    "s_bcnt1_i32_b64 s40, exec\n"                                                         \
+	    "s_lshl1_add_u32 %[cur], s40, %[cur]\n"                                               \
+	    "s_add_u32 %[np], %[np], s40\n"                                                       \
+	    "s_mov_b64 exec, s[56:57]\n"                                                          \
+	    "v_cmp_ge_u32 vcc, %[p], %[hi]\n"             /* range done                        */ \
+	    "s_andn2_b64 %[act], %[act], vcc\n"                                                   \
+	    "s_mov_b64 exec, %[act]\n"                                                            \
+	    ".endr\n"                                                                             \
+	    "s_branch .Lround%=\n"                                                                \
+	    ".Lout%=:\n"                                                                          \
+	    "s_waitcnt vmcnt(0) lgkmcnt(0)\n"                                                     \
+	    "s_mov_b64 exec, s[38:39]\n"                                                          \
+	    : [p] "+v"(p), [cp] "+v"(cp), [nb] "+v"(nb), [last] "+v"(last), [ncp] "+v"(ncp), [fill] "+v"(fill),  \
+	      [d0] "+v"(data0), [d1] "+v"(data1), [act] "=&s"(act_out), [req] "=&s"(req_out), [cur] "=&s"(cur_out), [np] "=&s"(np_out) \
+	    : [actin] "s"(uni64(act)), [reqin] "s"(uni64(req)), [curin] "s"(uni32(log.cur)), [sbase] "s"(uni64((unsigned long long)(uintptr_t)log.base)), \
+	      [hi] "v"(end), [rbase] "v"(ring_a), [tb] "v"(tb), [rmask] "s"(RING - 1), [rrows] "s"(RING - 4), [basea] "s"(label_bytes), \
+	      [high] "s"(HIGH), [room] "s"(RING - 8), [tprep] "s"(W.tprep), [fcont] "s"(first_cont), [maxcp] "s"(max_cp) \
+	    : "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "s38", "s39", "s40", "s41", "s42", "s43", \
+	      "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "vcc", "scc", "memory")
+
 // ---- closed-vocabulary occurrence counting (row f1) on the stream image --------------------------
 // What ExtractCandidates + Trie::AddString add up (GetTokens.cpp:21-27, Trie.cpp:114-128): every code
 // point position of every document starts a window of up to max_cp code points, and every
@@ -1163,11 +1265,13 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 // log as in scan_ranges_kernel.  A walk starts at every byte that starts a code point
 // (code < first_cont: trie.h) and is no separator; it stops at a miss, a leaf, a separator, or when
 // a (max_cp + 1)-th code point would start.  No range needs its neighbour: nothing to repair.
-template <uint32_t RING, uint32_t K> // K: lookups per round (W.round), unrolled
+template <uint32_t RING, uint32_t K, bool ASM> // K: lookups per round (W.round), unrolled; ASM: TOK_COUNT_ASM, else the C++ loop
 __global__ void __launch_bounds__(1024) count_ends_kernel(StreamTrieDev T, StreamWork W, StreamDev Qd, uint32_t first_cont,
-                                                          uint32_t max_cp, unsigned long long *positions) {
+                                                          uint32_t max_cp, unsigned long long *positions, uint32_t counter_at) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char count_ends_smem[];
-	__shared__ uint32_t s_positions;
+	// (no static LDS: the assembly takes a slot index for the LDS address of its label, so the image
+	// starts at LDS address 0 and the workgroup's position counter sits behind the rings)
+	uint32_t &s_positions = *reinterpret_cast<uint32_t *>(count_ends_smem + counter_at);
 	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)count_ends_smem;
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = uni32(threadIdx.x >> 6);
@@ -1186,13 +1290,19 @@ __global__ void __launch_bounds__(1024) count_ends_kernel(StreamTrieDev T, Strea
 	__syncthreads();
 	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
 	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
-	LDS_AS unsigned char *ring = lds + ((label_bytes + info_bytes + 127) & ~127u) + (wave * 64 + lane) * RING;
+	if (ASM && (uint32_t)(uintptr_t)lds != 0) { // (as scan_ranges_kernel: reported, never ignored)
+		if (threadIdx.x == 0) Qd.cursor[1] = 1u;
+		return;
+	}
+	// ring rows of one dword per lane, as in scan_ranges_kernel
+	LDS_AS unsigned char *ring = lds + ((label_bytes + info_bytes + 127) & ~127u) + wave * (64 * RING) + lane * 4;
+	auto ring_at = [&](uint32_t pos) { return ring + ((pos & (RING - 4)) << 6) + (pos & 3u); };
 	DirectLog log;
 	log.open_own(Qd, blockIdx.x * waves + wave);
 	const uint32_t total_waves = gridDim.x * waves;
 	const uint32_t rows = W.range_bytes + W.halo;
 	constexpr uint32_t high = kBatchEntries * 2 - 128 * K; // a round adds at most 64 K entries
-	uint32_t npos = 0;
+	uint32_t npos = 0, npos_wave = 0; // per lane (C++ loop) / per wave (assembly)
 	for (uint32_t wb = blockIdx.x * waves + wave; wb * 64 < W.nranges; wb += total_waves) {
 		const uint32_t g = wb * 64 + lane;
 		const uint8_t *blk = W.tprep + (size_t)wb * rows * 64 + lane * 8;
@@ -1208,17 +1318,39 @@ __global__ void __launch_bounds__(1024) count_ends_kernel(StreamTrieDev T, Strea
 #pragma unroll
 			for (uint32_t k = 0; k < RING / 8; k++) {
 				const u32x2 x = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
-				*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = x;
+				*(LDS_AS uint32_t *)ring_at(fill) = x.x;
+				*(LDS_AS uint32_t *)ring_at(fill + 4) = x.y;
 				fill += 8;
 			}
 		}
 		wave_sync();
+		if constexpr (ASM) {
+			const uint32_t ring_a = (uint32_t)(uintptr_t)ring;
+			const uint32_t tb = (uint32_t)((size_t)wb * rows * 64 + lane * 8); // (the transposed copy is below 4 GiB)
+			unsigned long long act = __builtin_amdgcn_ballot_w64(active), req = 0;
+			uint32_t data0 = 0, data1 = 0, cp = 0;
+			while (act != 0) {
+				unsigned long long act_out, req_out;
+				uint32_t cur_out, np_out;
+				if constexpr (K == 4) TOK_COUNT_ASM(4, high);
+				else if constexpr (K == 5) TOK_COUNT_ASM(5, high);
+				else if constexpr (K == 6) TOK_COUNT_ASM(6, high);
+				else if constexpr (K == 7) TOK_COUNT_ASM(7, high);
+				else TOK_COUNT_ASM(8, high);
+				act = act_out, req = req_out;
+				log.cur = cur_out;
+				npos_wave += np_out;
+				log.roll_if_full(Qd, lane, high);
+			}
+			continue;
+		}
 		bool req = false;
 		u32x2 data = {0, 0};
 		unsigned long long act = __builtin_amdgcn_ballot_w64(active);
 		while (act != 0) {
 			if (req) {
-				*(LDS_AS u32x2 *)(ring + (fill & (RING - 1))) = data;
+				*(LDS_AS uint32_t *)ring_at(fill) = data.x;
+				*(LDS_AS uint32_t *)ring_at(fill + 4) = data.y;
 				fill += 8;
 			}
 			req = active && (fill - p) <= RING - 8; // (nothing before p is read again)
@@ -1228,7 +1360,7 @@ __global__ void __launch_bounds__(1024) count_ends_kernel(StreamTrieDev T, Strea
 			for (uint32_t it = 0; it < K; it++) {
 				bool ended = false;
 				if (active) {
-					const uint32_t c = ring[(p + d) & (RING - 1)];
+					const uint32_t c = *ring_at(p + d);
 					const bool lead = c < first_cont; // a code point (or the separator) starts here
 					if (d == 0 && (!lead || c == 0)) {
 						p++; // no window starts inside a code point or on a separator
@@ -1260,6 +1392,7 @@ __global__ void __launch_bounds__(1024) count_ends_kernel(StreamTrieDev T, Strea
 	}
 	log.close(Qd, lane);
 	for (int o = 32; o > 0; o >>= 1) npos += __shfl_xor(npos, o, 64);
+	npos += npos_wave;
 	if (lane == 0 && npos) atomicAdd(&s_positions, npos);
 	__syncthreads();
 	if (threadIdx.x == 0 && s_positions) atomicAdd(positions, (unsigned long long)s_positions);
@@ -1714,20 +1847,34 @@ void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const Strea
 void launch_count_ends(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
                        uint32_t first_cont, uint32_t max_cp, unsigned long long *positions, hipStream_t stream) {
 	auto go = [&](auto kernel) {
-		// (this kernel has a static LDS word beside the dynamic block)
+		// (the workgroup's position counter sits in 16 bytes behind the plan's block)
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-		                          (int)plan.lds_bytes);
-		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, T, W, Q,
-		                   first_cont, max_cp, positions);
+		                          (int)plan.lds_bytes + 16);
+		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes + 16, stream, T, W, Q,
+		                   first_cont, max_cp, positions, plan.lds_bytes);
 	};
+	static const bool use_asm = [] {
+		const char *e = getenv("TOKSCORE_ASM");
+		return !(e && atoi(e) == 0);
+	}();
 	auto pick = [&](auto ring) {
 		constexpr uint32_t R = decltype(ring)::value;
-		switch (plan.round) {
-		case 4: go(&count_ends_kernel<R, 4>); break;
-		case 5: go(&count_ends_kernel<R, 5>); break;
-		case 6: go(&count_ends_kernel<R, 6>); break;
-		case 7: go(&count_ends_kernel<R, 7>); break;
-		default: go(&count_ends_kernel<R, 8>); break; // (plan_ranges_scan: 4 .. 8)
+		if (use_asm) {
+			switch (plan.round) {
+			case 4: go(&count_ends_kernel<R, 4, true>); break;
+			case 5: go(&count_ends_kernel<R, 5, true>); break;
+			case 6: go(&count_ends_kernel<R, 6, true>); break;
+			case 7: go(&count_ends_kernel<R, 7, true>); break;
+			default: go(&count_ends_kernel<R, 8, true>); break; // (plan_ranges_scan: 4 .. 8)
+			}
+		} else {
+			switch (plan.round) {
+			case 4: go(&count_ends_kernel<R, 4, false>); break;
+			case 5: go(&count_ends_kernel<R, 5, false>); break;
+			case 6: go(&count_ends_kernel<R, 6, false>); break;
+			case 7: go(&count_ends_kernel<R, 7, false>); break;
+			default: go(&count_ends_kernel<R, 8, false>); break;
+			}
 		}
 	};
 	if (plan.ring == 32) pick(std::integral_constant<uint32_t, 32>{});
