@@ -119,3 +119,37 @@ def test_one_workgroup_sees_more_than_a_16_bit_row_holds(monkeypatch):
     got = _gpu_counts(names, (corpus, off), 4)
     assert int(exp[0].max()) > 40_000
     assert np.array_equal(got[0], exp[0]) and got[1] == exp[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("longest,extra", [(24, 300), (45, 300), (60, 40), (90, 40)])
+def test_longer_tokens_take_the_wider_rings(longest, extra):
+    """Tokens of up to 24 / 45 / 90 bytes: 64- and 128-byte lane rings and other round lengths in the
+    assembly loops of the scan and of the counting kernel (the bench vocabulary only sees 32-byte
+    rings with rounds of 7)."""
+    corpus, off = synth.wiki_like(1_200_000, seed=41)
+    tokens = synth.build_vocab(corpus[:300_000], 3000)
+    rng = np.random.default_rng(longest)
+    raw = bytes(corpus)
+    for _ in range(extra):  # strings cut from the corpus, so that they do occur
+        n = int(rng.integers(12, longest + 1))
+        at = int(rng.integers(0, len(raw) - n))
+        piece = raw[at:at + n]
+        if b"\0" not in piece:
+            tokens.append(piece.lower())
+    tokens = list(dict.fromkeys(tokens))
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        exp = voc.score(corpus, off, threads=8)
+        got = s.score()
+        assert np.array_equal(got[0], exp[0]) and got[1:] == exp[1:]
+        if longest <= 60:
+            assert s.info().scan_path == 2
+        expc = voc.count_occurrences(corpus, off, longest, threads=8)
+        gotc = s.count_occurrences(longest)
+        assert np.array_equal(gotc[0], expc[0]) and gotc[1] == expc[1]
+    finally:
+        s.close()

@@ -1483,6 +1483,12 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		uint32_t limit;
 		if (c->knob_incr_div) {
 			limit = c->nchunks / (uint32_t)c->knob_incr_div;
+		} else if (c->scan_path != 2) {
+			// the tile scan (vocabularies the stream image cannot hold: config 5's CJK-heavy one) takes
+			// 3 ms per GB for a full evaluation and 0.1 ms for a partial pass over a few thousand
+			// chunks: round 1's rule, a third of the chunks.  (The estimate below, made for the stream
+			// scan, sent 72 % of config 5's moves to full evaluations: 443 instead of 2,400 moves/s.)
+			limit = c->nchunks / 3;
 		} else {
 			const double full_us = 50.0 + 0.95e-6 * (double)c->total; // 0.95 us per MB
 			const double fixed_us = 2 * 110.0, per_chunk_us = 2 * 0.3;
