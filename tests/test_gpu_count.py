@@ -153,3 +153,41 @@ def test_longer_tokens_take_the_wider_rings(longest, extra):
         assert np.array_equal(gotc[0], expc[0]) and gotc[1] == expc[1]
     finally:
         s.close()
+
+
+_ASM0_CHILD = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+import oracle_ffi as O
+import tokenizer_amd as ta
+from tokenizer_amd import synth
+corpus, off = synth.wiki_like(1_000_000, seed=43)
+tokens = synth.build_vocab(corpus[:300_000], 3000, lowercase=False)
+voc = O.OracleVocab(*synth.pack_vocab(tokens))
+s = ta.Scorer(0)
+s.set_vocab(*synth.pack_vocab(tokens))
+s.set_corpus(corpus, off)
+exp = voc.score(corpus, off, threads=8)
+for _ in range(2):
+    got = s.score()
+    assert np.array_equal(got[0], exp[0]) and got[1:] == exp[1:], "score"
+assert s.info().scan_path == 2
+expc = voc.count_occurrences(corpus, off, 8, threads=8)
+gotc = s.count_occurrences(8)
+assert np.array_equal(gotc[0], expc[0]) and gotc[1] == expc[1], "count"
+s.close()
+print("asm0 ok")
+"""
+
+
+def test_cpp_loops_behind_tokscore_asm_0():
+    """TOKSCORE_ASM=0 (read once per process, hence a child process: one, for this test only) puts the
+    C++ loops in the place of the assembly ones in scan_ranges_kernel and count_ends_kernel; same
+    results."""
+    import subprocess
+    import sys
+    env = dict(os.environ, TOKSCORE_ASM="0", TOKSCORE_SCAN="stream")
+    r = subprocess.run([sys.executable, "-c", _ASM0_CHILD, os.path.dirname(HERE), HERE], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "asm0 ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
