@@ -345,8 +345,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # HIP events, recorded by the library on the stream its kernels run on and read after the timed
-    # region (no host sync inside it): around the scan kernel of every 4th timed launch.  Marking
+    # HIP events, set by the library on the stream its kernels run on and read after the timed
+    # region (no host sync inside it): on the scan kernel of every 4th timed launch (the stream scan's
+    # dispatch carries them itself; the other scan paths have a record before and after).  Marking
     # every launch, and every kernel of it, costs 8 % of a step (a record holds the stream for
     # 3 - 4 us; tools/dbg/ab_steps.py), which a caller without a profiler does not pay.
     sample_every = 4 if args.steps >= 8 else 1
@@ -401,7 +402,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": {1: "scan_tile_kernel", 2: "scan_ranges_kernel"}.get(int(info.scan_path), "scan_generic_kernel"),
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": scan_avg_ms,
-                         "kernel_ms_from": "HIP events around %d of the %d timed launches (every %s)"
+                         "kernel_ms_from": "HIP events attached to the kernel's dispatch (hipExtLaunchKernel: its own begin and end) on %d of the %d timed launches (every %s)"
                                            % (len(scan_ms), args.steps, "one" if sample_every == 1 else "%dth" % sample_every),
                          "eval_kernels_ms": float(np.mean(eval_ms)),
                          "eval_kernels_ms_from": "5 launches after the timed region, every kernel marked",

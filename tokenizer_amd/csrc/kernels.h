@@ -192,8 +192,12 @@ struct OutInit {
 	uint32_t V = 0;
 	unsigned long long D = 0, total_bytes = 0;
 };
+// ev_start / ev_stop (both or neither): events that take the kernel's own begin and end from its
+// dispatch (hipExtLaunchKernel), not the times a record placed before and after it would read -- those
+// include what the stream waits around a record, about 4 us of a 90 us kernel.
 void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
-                        hipStream_t stream, const OutInit &init = OutInit{});
+                        hipStream_t stream, const OutInit &init = OutInit{}, hipEvent_t ev_start = nullptr,
+                        hipEvent_t ev_stop = nullptr);
 // out[slot_id[s]] += occurrences of slot s in the stream, out[total_index] += entries on counted slots
 void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
                             uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip = false);

@@ -31,6 +31,7 @@
 // as the 16-bit index of the slot it ended on; hist_slots_kernel bins slot indices and
 // slab_reduce_map_kernel turns slots into ids once per evaluation.
 #include "kernels.h"
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdlib>
@@ -1813,11 +1814,14 @@ bool plan_ranges_scan(uint32_t nslots, uint64_t max_len, uint32_t num_cus, Strea
 }
 
 void launch_scan_ranges(const StreamTrieDev &T, const StreamWork &W, const StreamDev &Q, const StreamScanPlan &plan,
-                        hipStream_t stream, const OutInit &init) {
+                        hipStream_t stream, const OutInit &init, hipEvent_t ev_start, hipEvent_t ev_stop) {
 	auto go = [&](auto kernel) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 		                          (int)plan.lds_bytes);
-		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, T, W, Q, init);
+		if (ev_start && ev_stop)
+			hipExtLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, ev_start, ev_stop, 0u,
+			                      T, W, Q, init);
+		else hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, T, W, Q, init);
 	};
 	static const bool use_asm = [] {
 		const char *e = getenv("TOKSCORE_ASM");

@@ -863,14 +863,17 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		const bool ready = first_batches != 0 && c->stream_ready == first_batches;
 		c->stream_ready = 0;
 		if (!ready) launch_prepare(d_out, (uint32_t)c->V, c->D, c->total, Q, s, first_batches);
-		HIP_TRY(c, mark(1));
 		const StreamWork W = stream_work(c, false);
 		if (c->d_tprep) {
+			// the scan's two marks come from its dispatch itself (kernels.h)
 			OutInit init;
 			if (ready) init = OutInit{d_out, (uint32_t)c->V, c->D, c->total};
-			launch_scan_ranges(stream_trie_dev(c), W, Q, c->rplan, s, init);
-		} else launch_scan_stream(stream_trie_dev(c), W, Q, c->splan, s);
-		HIP_TRY(c, mark(2));
+			launch_scan_ranges(stream_trie_dev(c), W, Q, c->rplan, s, init, ev ? ev[1] : nullptr, ev ? ev[2] : nullptr);
+		} else {
+			HIP_TRY(c, mark(1));
+			launch_scan_stream(stream_trie_dev(c), W, Q, c->splan, s);
+			HIP_TRY(c, mark(2));
+		}
 		// ranges whose entry was not the previous range's exit (none while the vocabulary stays as it is)
 		c->fix_epoch = c->fix_epoch % 65535u + 1u;
 		launch_fixup_and_histogram_slots(stream_trie_dev(c), W, c->d_range_state + 2 * (size_t)c->nranges, c->d_cursor + 2, c->fix_epoch, Q,
