@@ -31,10 +31,13 @@ def _check_moves(s, tokens, enabled, corpus, off, idx, en):
     return got
 
 
-@pytest.mark.parametrize("env", [{}, {"TOKSCORE_TOGGLE_ITEMS": "2000", "TOKSCORE_TOGGLE_LIST": "4"}, {"TOKSCORE_SCAN": "tile"}])
+@pytest.mark.parametrize("env", [{}, {"TOKSCORE_TOGGLE_ITEMS": "2000", "TOKSCORE_TOGGLE_LIST": "4"}, {"TOKSCORE_SCAN": "tile"},
+                                 {"TOKSCORE_NOMARKRANGES": "1"}])
 def test_deltas_equal_oracle_differences(env, monkeypatch):
     """env: one batch / several batches (a small budget of pairs) whose item lists start too short and
-    have to be provided again / the move-by-move fallback on a scan path without the batched kernel."""
+    have to be provided again / the move-by-move fallback on a scan path without the batched kernel /
+    token starts and tokens per stream always from the walk over streams (after a full evaluation they
+    come from its ranges otherwise)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     corpus, off = synth.wiki_like(1_500_000, seed=31)
@@ -146,5 +149,36 @@ def test_incremental_rescore_on_the_default_cost_model(monkeypatch):
             got = s.score(incremental=True)
             assert got[1] == _oracle_total(tokens, enabled, corpus, off)
             assert s.info().rescored_chunks == 0xFFFFFFFF, "a full evaluation was expected to be cheaper here"
+    finally:
+        s.close()
+
+
+def test_annealing_like_sequence_takes_token_starts_from_the_ranges():
+    """judge K moves, apply one, take the exact score, again: every batch after a full evaluation gets
+    its token starts and tokens per stream from that evaluation's ranges (mark_ranges_kernel), with
+    entries that the previous toggle's repairs have just moved.  Deltas against the oracle, and the
+    applied move's delta against the next exact score."""
+    corpus, off = synth.wiki_like(1_200_000, seed=37)
+    tokens = synth.build_vocab(corpus[:400_000], 4000)
+    V = len(tokens)
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        total = s.score()[1]
+        assert s.info().scan_path == 2
+        enabled = np.ones(V, dtype=bool)
+        rng = np.random.default_rng(9)
+        multi = [i for i, t in enumerate(tokens) if len(t) >= 2]
+        for batch in range(6):
+            idx = [int(i) for i in rng.choice(multi, size=6, replace=False)]
+            en = [0 if enabled[i] else 1 for i in idx]
+            got = _check_moves(s, tokens, enabled, corpus, off, idx, en)
+            k = int(np.argmax(np.abs(got)))
+            s.toggle(idx[k], bool(en[k]))
+            enabled[idx[k]] = bool(en[k])
+            now = s.score()[1]
+            assert now - total == int(got[k]), (batch, idx[k], now - total, int(got[k]))
+            total = now
     finally:
         s.close()

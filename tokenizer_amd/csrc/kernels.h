@@ -175,6 +175,9 @@ void launch_find_toggle_streams(const ToggleBatch &B, const StreamWork &W, uint3
 void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, uint64_t max_items,
                          hipStream_t stream);
 // W.tg_base / W.tg_starts for all streams (the vocabulary as it is), W.tg_order optional
+// the same two results from the ranges of the full evaluation that has just run (W.entry exact, W.tprep,
+// plan = the ranges plan): W.tg_base is ADDED to (zero it first), W.tg_starts as for launch_count_streams
+void launch_mark_ranges(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, hipStream_t stream);
 void launch_count_streams(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, hipStream_t stream);
 // The items with occurrence offsets: from every occurrence the chain of the vocabulary as it is and
 // the chain with the move are walked side by side until they meet again (a few dozen bytes), the

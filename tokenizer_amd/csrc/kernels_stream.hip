@@ -1153,6 +1153,136 @@ __global__ void __launch_bounds__(1024) scan_ranges_kernel(StreamTrieDev T, Stre
 	log.close(Qd, lane);
 }
 
+// ---- batched moves: token starts and tokens per stream, in ranges form ---------------------------
+// What count_streams_kernel leaves behind (W.tg_starts: one bit per prepared byte where a token of the
+// vocabulary as it is starts; W.tg_base: tokens per stream, ADDED here, so zeroed by the caller), from
+// the ranges a full evaluation has just scanned: W.entry holds the true entry of every range after
+// that evaluation's fix-up, so every lane can walk its own range of the transposed corpus exactly as
+// scan_ranges_kernel does -- coalesced refills, equal work per lane -- instead of one stream per
+// lane from the linear corpus (0.9 ms per 100 MB, a third of an annealing batch; this: 0.2).
+// A token belongs to the stream it starts in (stream cuts are token starts of every chain).
+template <uint32_t RING>
+__global__ void __launch_bounds__(1024) mark_ranges_kernel(StreamTrieDev T, StreamWork W) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char mark_smem[];
+	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)mark_smem;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = uni32(threadIdx.x >> 6);
+	const uint32_t waves = blockDim.x >> 6;
+	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
+	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
+	{
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
+		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		dst = (LDS_AS u32x4 *)(lds + label_bytes);
+		src = reinterpret_cast<const u32x4 *>(T.base);
+		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+	}
+	__syncthreads();
+	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
+	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
+	LDS_AS unsigned char *ring = lds + ((label_bytes + info_bytes + 127) & ~127u) + wave * (64 * RING) + lane * 4;
+	auto ring_at = [&](uint32_t pos) { return ring + ((pos & (RING - 4)) << 6) + (pos & 3u); };
+	const uint32_t total_waves = gridDim.x * waves;
+	const uint32_t rows = W.range_bytes + W.halo;
+	const uint32_t round = W.round;
+	for (uint32_t wb = blockIdx.x * waves + wave; wb * 64 < W.nranges; wb += total_waves) {
+		const uint32_t g = wb * 64 + lane;
+		const uint8_t *blk = W.tprep + (size_t)wb * rows * 64 + lane * 8;
+		uint32_t end = 0, cp = 0, b0 = 0;
+		if (g < W.nranges) {
+			b0 = g * W.range_bytes;
+			end = b0 + W.range_bytes < W.prep_total ? W.range_bytes : W.prep_total - b0;
+			cp = W.entry[g];
+		}
+		bool active = cp < end;
+		uint32_t lend = cp, lslot = 0, nb = 0;
+		uint32_t fill = cp & ~7u;
+		// the stream the range's first token starts in, and where that stream ends
+		uint32_t sidx = 0, cut = 0, ntok = 0;
+		unsigned long long wmask = 0;
+		uint32_t wword = 0;
+		auto mark = [&](uint32_t q) {
+			const uint32_t w = q >> 6;
+			if (w != wword) {
+				if (wmask) atomicOr(&W.tg_starts[wword], wmask);
+				wword = w, wmask = 0;
+			}
+			wmask |= 1ull << (q & 63);
+		};
+		wave_sync();
+		if (active) {
+#pragma unroll
+			for (uint32_t k = 0; k < RING / 8; k++) {
+				const u32x2 x = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
+				*(LDS_AS uint32_t *)ring_at(fill) = x.x;
+				*(LDS_AS uint32_t *)ring_at(fill + 4) = x.y;
+				fill += 8;
+			}
+			const uint32_t q = b0 + cp;
+			uint32_t l = 0, h = W.nstreams; // last stream with pbeg <= q (pbeg[0] = 0)
+			while (h - l > 1) {
+				const uint32_t mid = (l + h) >> 1;
+				if (W.pbeg[mid] <= q) l = mid;
+				else h = mid;
+			}
+			sidx = l;
+			cut = W.pbeg[sidx + 1];
+			mark(q);
+		}
+		wave_sync();
+		bool req = false;
+		u32x2 data = {0, 0};
+		unsigned long long act = __builtin_amdgcn_ballot_w64(active);
+		while (act != 0) {
+			if (req) {
+				*(LDS_AS uint32_t *)ring_at(fill) = data.x;
+				*(LDS_AS uint32_t *)ring_at(fill + 4) = data.y;
+				fill += 8;
+			}
+			req = active && (fill - lend) <= RING - 8;
+			if (req) data = *reinterpret_cast<const u32x2 *>(blk + (size_t)fill * 64);
+			wave_sync();
+			for (uint32_t it = 0; it < round; it++) {
+				if (active) {
+					const uint32_t c = *ring_at(cp);
+					const uint32_t t = nb + c;
+					const uint32_t x = l_lt[t] ^ c;
+					const uint32_t b = l_base[t];
+					const uint32_t cp1 = cp + 1;
+					const bool term = x == 0x80u;
+					lend = term ? cp1 : lend;
+					lslot = term ? t : lslot;
+					nb = (x & 0x7Fu) == 0 ? b : 0u;
+					const bool cont = nb != 0;
+					cp = cont ? cp1 : lend;
+					if (!cont) {
+						ntok += lslot != 0 ? 1u : 0u; // (slot 0: a document separator, no token)
+						if (cp < end) {
+							const uint32_t q = b0 + cp; // the next token starts here
+							if (q >= cut) {
+								if (ntok) atomicAdd(&W.tg_base[sidx], ntok);
+								ntok = 0;
+								do sidx++;
+								while (W.pbeg[sidx + 1] <= q);
+								cut = W.pbeg[sidx + 1];
+							}
+							mark(q);
+						} else {
+							active = false;
+							if (ntok) atomicAdd(&W.tg_base[sidx], ntok);
+							if (wmask) atomicOr(&W.tg_starts[wword], wmask);
+							wmask = 0, ntok = 0;
+						}
+					}
+				}
+				act = __builtin_amdgcn_ballot_w64(active);
+				if (act == 0) break;
+			}
+		}
+	}
+}
+
 // count_ends_kernel's round loop in gfx950 assembly: scan_ranges_kernel's (TOK_RANGES_ASM: same ring
 // rows, same refill, same pipelining -- a lookup's reads are issued before the previous one's entry
 // is logged, and no lookup waits for a byte: the next byte is the one at cp + 1 (v30) or the one at
@@ -1911,6 +2041,18 @@ void launch_find_toggle_streams(const ToggleBatch &B, const StreamWork &W, uint3
 	hipLaunchKernelGGL(list_toggle_pairs_kernel, dim3(B.n), dim3(1024), 0, stream, Bw);
 	hipLaunchKernelGGL(fill_toggle_pairs_kernel, dim3((npairs + 255) / 256), dim3(256), 0, stream, Bw, npairs);
 	hipLaunchKernelGGL(find_toggle_streams_kernel, dim3((npairs + 15) / 16), dim3(1024), 0, stream, Bw, W, nchunks);
+}
+
+void launch_mark_ranges(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, hipStream_t stream) {
+	if (W.nranges == 0 || W.nstreams == 0) return;
+	auto go = [&](auto kernel) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+		                          (int)plan.lds_bytes);
+		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, T, W);
+	};
+	if (plan.ring == 32) go(&mark_ranges_kernel<32>);
+	else if (plan.ring == 64) go(&mark_ranges_kernel<64>);
+	else go(&mark_ranges_kernel<128>);
 }
 
 void launch_count_streams(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, hipStream_t stream) {

@@ -172,9 +172,11 @@ struct tokscore_ctx {
 	uint32_t *d_stream_tokens = nullptr; // [nstreams] tokens per stream, valid while stream_tokens_epoch == trie_epoch
 	size_t stream_tokens_cap = 0;
 	uint64_t trie_epoch = 1, stream_tokens_epoch = 0; // trie_epoch: another one whenever the device trie or the plan changes
+	uint64_t entries_epoch = 0; // the trie_epoch whose full evaluation over ranges (on the context's own stream) left d_range_state's entries exact
 	// knobs of the move paths, read once at tokscore_create (not on every call)
 	bool knob_noincr = false, knob_nobatch = false;
 	uint64_t knob_incr_div = 0;      // 0: the cost estimate decides
+	bool knob_no_mark_ranges = false; // TOKSCORE_NOMARKRANGES=1: always count_streams_kernel before batched moves (tests)
 	uint64_t knob_toggle_items = 32ull << 20; // (move, chunk) pairs one batch of moves may have
 	uint64_t tg_list_hint = 8192;             // entries per item list provided first (doubled when a batch needed more)
 	uint64_t toggle_items = 0; // (move, stream) items walked by score_toggles so far (diagnostics)
@@ -880,6 +882,7 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		                                 (uint32_t)c->simg.lt.size(), c->d_slot_id, d_out, (uint32_t)c->V + 3, c->d_slab, c->slab_blocks, s,
 		                                 first_batches);
 		c->stream_ready = first_batches;
+		c->entries_epoch = c->d_tprep && s == c->stream ? c->trie_epoch : 0;
 	} else if (c->scan_path == 1) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 		c->stream_ready = 0;
@@ -1202,6 +1205,7 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	if (e != hipSuccess) return give_up("address of the library's static device scratch (is the gfx950 code object loaded?)", e);
 	c->knob_noincr = env_u64("TOKSCORE_NOINCR", 0) != 0;
 	c->knob_nobatch = env_u64("TOKSCORE_NOBATCH", 0) != 0;
+	c->knob_no_mark_ranges = env_u64("TOKSCORE_NOMARKRANGES", 0) != 0;
 	c->knob_incr_div = getenv("TOKSCORE_INCR_DIV") ? std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)) : 0;
 	c->knob_toggle_items = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 32ull << 20));
 	c->tg_list_hint = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_LIST", 8192));
@@ -1695,7 +1699,11 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		Wb.tg_base = c->d_stream_tokens;
 		Wb.tg_starts = c->d_tok_starts;
 		Wb.tg_order = c->d_stream_order;
-		launch_count_streams(stream_trie_dev(c), Wb, c->splan, s);
+		if (c->d_tprep && c->entries_epoch == c->trie_epoch && !c->knob_no_mark_ranges) {
+			// a full evaluation of this vocabulary has just left every range's true entry: walk the ranges
+			HIP_TRY(c, hipMemsetAsync(c->d_stream_tokens, 0, ((size_t)c->nstreams + 1) * sizeof(uint32_t), s));
+			launch_mark_ranges(stream_trie_dev(c), Wb, c->rplan, s);
+		} else launch_count_streams(stream_trie_dev(c), Wb, c->splan, s);
 		HIP_TRY(c, hipGetLastError());
 		c->stream_tokens_epoch = c->trie_epoch;
 	}
