@@ -211,6 +211,24 @@ def moves_per_sec(scorer, tokens, corpus, off):
         scorer.toggle(int(batches[1][k]), True)
         batched_exact = batched_exact and int(deltas[0][k]) == tt - base_tt
     scorer.score(out=buf)
+    # (iv) the same call inside an annealing-like loop: 64 moves judged, the best one applied, the exact
+    # score taken, again -- every call then starts from a changed vocabulary
+    state = np.ones(len(tokens), dtype=bool)
+    loop_batches = [rng.choice(multi, size=64, replace=False) for _ in range(21)]
+    t0 = 0.0
+    for n, b in enumerate(loop_batches):
+        if n == 1:
+            t0 = time.perf_counter()  # (the first batch is the warm-up)
+        en = [0 if state[i] else 1 for i in b]
+        d = scorer.score_toggles(b, en)
+        k = int(np.argmin(d))
+        state[b[k]] = bool(en[k])
+        scorer.toggle(int(b[k]), bool(en[k]))
+        scorer.score(out=buf)
+    anneal_like = 64 * (len(loop_batches) - 1) / (time.perf_counter() - t0)
+    for i in np.nonzero(~state)[0]:  # back to the full vocabulary
+        scorer.toggle(int(i), True)
+    scorer.score(out=buf)
     run(True, picks[:2])
     inc = run(True, picks[2:])
     full = run(False, picks[2:42])
@@ -224,6 +242,7 @@ def moves_per_sec(scorer, tokens, corpus, off):
     host = st.gen_cnt / (time.perf_counter() - t0)
     gen.close()
     return {"gpu_score_toggles_k64": batched, "gpu_score_toggles_k64_exact": batched_exact,
+            "gpu_anneal_like_loop_k64": anneal_like,
             "gpu_toggle_incremental_rescore": inc, "gpu_toggle_full_rescore": full,
             "host_dag_loop": host, "host_threads": threads, "host_candidates": n_cand,
             "note": "moves/s; GPU: this shard and vocabulary, result on the host after every move"}
