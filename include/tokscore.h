@@ -204,12 +204,27 @@ typedef struct {
 	uint64_t chunks;          /* wave work units of the scan kernel */
 	uint32_t slot_bits;       /* packed slot = label:8 | valid:1 | base:slot_bits, then id:id_bits */
 	uint32_t id_bits;
-	uint32_t scan_path;       /* 2 = LDS stream scan, 1 = LDS tile scan kernel, 0 = generic global-memory scan */
+	uint32_t scan_path;       /* what the last full evaluation ran on: 2 = LDS stream scan (one range of the
+	                           * corpus per lane, trie / automaton image in LDS), 1 = LDS tile scan kernel,
+	                           * 0 = generic global-memory scan */
 	uint32_t rescored_chunks; /* chunks re-scanned by the last tokscore_score_incremental;
 	                           * UINT32_MAX when it ran (or fell back to) a full evaluation */
 	uint64_t toggle_streams;  /* streams walked (twice each) by the batched path of tokscore_score_toggles
 	                           * since the context was created; unchanged by a call the move-by-move
 	                           * fallback served */
+	/* the automaton scan (one transition per corpus byte; tokenizer_amd/csrc/dfa.h), which serves full
+	 * evaluations whenever its image can be built for the vocabulary; 0 everywhere when it cannot */
+	uint64_t dfa_slots;         /* 4-byte slots of the image, real + virtual + empty */
+	uint64_t dfa_virtual_slots;
+	uint32_t dfa_lds_slots;     /* its hot-first prefix staged in LDS; the rest is read from L2 */
+	uint32_t dfa_active;        /* 1: the last full evaluation ran on it */
+	uint32_t dfa_chains;        /* ranges of the corpus each lane steps side by side */
+	uint32_t dfa_range_bytes;
+	uint32_t base_scan_path;    /* the plan's own scan (incremental re-scores, moves, evaluations after toggles) */
+	uint32_t reserved0;
+	double dfa_hot_fraction;    /* share of the hotness sample's lookups that fall on the LDS prefix */
+	double dfa_build_ms;        /* host time of the last image build */
+	double dfa_plan_ms;         /* image + prepared corpus + buffers, once per corpus and vocabulary */
 } tokscore_info;
 int tokscore_get_info(tokscore_ctx *ctx, tokscore_info *info);
 
@@ -244,6 +259,18 @@ int tokscore_probe_read_bandwidth(tokscore_ctx *ctx, uint64_t bytes, uint32_t re
  * prefix of text[0..n).  *len = 0 when none.  Never used by any scoring entry point. */
 int tokscore_hosttrie_longest(tokscore_ctx *ctx, const uint8_t *text, uint64_t n, uint64_t *len,
                               uint64_t *id);
+
+/* Host-side self-check of the scan automaton's builder (tokenizer_amd/csrc/dfa.h; no GPU involved,
+ * used by the CPU test-suite): builds the one-transition-per-byte image of the vocabulary as it is
+ * (toggles included) with the documents as the hotness sample, runs it over the documents on the
+ * host exactly as the scan kernel steps it, and returns what its events add up to -- counts[V+3]
+ * and total_tokens as tokscore_score defines them (SolutionFile.cpp:83-100, main.cpp:38-43).
+ * max_slots = 0: the library's default limit.  stats (may be NULL): slots, real slots, virtual
+ * slots, codes, stride of the depth-1 rows, longest event list, sample steps, of those on virtual
+ * slots.  TOKSCORE_E_VOCAB when the image cannot be built (the scoring entry points then use the
+ * other scan paths).  Never used by any scoring entry point. */
+int tokscore_hostdfa_check(tokscore_ctx *ctx, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t max_slots,
+                           uint64_t *counts, uint64_t *total_tokens, uint64_t stats[8]);
 
 /* Contexts without a GPU, for the host-side checks above only: set_vocab and
  * hosttrie_longest work, every scoring call fails with TOKSCORE_E_NO_DEVICE. */

@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _scorer(env):
+    # a test that names one of the plan's scan paths means that path: the automaton scan (the default for
+    # full evaluations since round 3) is switched off unless the test asks for it
+    if "TOKSCORE_SCAN" in env and "TOKSCORE_DFA" not in env:
+        env = dict(env, TOKSCORE_DFA="0")
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -59,10 +63,24 @@ CONFIGS = [
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "300", "TOKSCORE_NOSNAP": "1"},
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "300", "TOKSCORE_TILE_BLOCKS": "8"},   # fewer workgroups than queue heads (a small partition)
     {"TOKSCORE_SCAN": "tile", "TOKSCORE_CHUNK": "2048", "TOKSCORE_TILE_BLOCKS": "1"},
-    {"TOKSCORE_SCAN": "stream"},                               # one byte stream per lane, trie image in LDS (the default)
+    {"TOKSCORE_SCAN": "stream"},                               # one byte stream per lane, trie image in LDS
     {"TOKSCORE_SCAN": "stream", "TOKSCORE_STREAM": "64", "TOKSCORE_SPC": "3"},    # shortest streams, ragged chunks
     {"TOKSCORE_SCAN": "stream", "TOKSCORE_STREAM": "1000", "TOKSCORE_WAVES": "4"},
 ]
+# the plan's own scan paths above run with the automaton scan (round 3, the default for full evaluations)
+# switched off; these run with it on: the library's defaults, fewer ranges per lane, and an LDS prefix so
+# short that most lookups and events go the way of slots beyond it
+for _c in CONFIGS:
+    _c["TOKSCORE_DFA"] = "0"
+DFA_CONFIGS = [
+    {},
+    {"TOKSCORE_DFA_CHAINS": "1"},
+    {"TOKSCORE_DFA_CHAINS": "2", "TOKSCORE_DFA_LDS": "600"},
+    {"TOKSCORE_SCAN": "tile", "TOKSCORE_DFA": "1", "TOKSCORE_DFA_LDS": "2000"},
+]
+# goldens the automaton does not take (the plan's scan serves them): documents with NUL bytes
+DFA_EXCEPT = {"nul_doc"}
+CONFIGS = CONFIGS + DFA_CONFIGS
 # goldens whose text has sync points and whose trie fits LDS: the stream scan must be the path taken
 STREAM_CASES = {"ascii_caps", "cjk_heavy", "short_docs", "prefix_greedy"}  # (wiki_annealed: 125k trie nodes, random_utf8: > 125 edge labels: tile scan)
 
@@ -78,10 +96,15 @@ def test_score_matches_reference_golden(case, cfg):
     assert tt == exp["total_tokens"]
     bad = np.nonzero(counts != exp["counts_vec"])[0]
     assert bad.size == 0, (case, CONFIGS[cfg], bad[:10], counts[bad[:10]], exp["counts_vec"][bad[:10]])
-    if CONFIGS[cfg]["TOKSCORE_SCAN"] == "tile":
-        assert info.scan_path == 1, "tile scan was expected to be selected"
-    if CONFIGS[cfg]["TOKSCORE_SCAN"] == "stream" and case in STREAM_CASES:
-        assert info.scan_path == 2, "stream scan was expected to be selected"
+    if CONFIGS[cfg].get("TOKSCORE_DFA") == "0":
+        assert info.dfa_active == 0
+        if CONFIGS[cfg]["TOKSCORE_SCAN"] == "tile":
+            assert info.scan_path == 1, "tile scan was expected to be selected"
+        if CONFIGS[cfg]["TOKSCORE_SCAN"] == "stream" and case in STREAM_CASES:
+            assert info.scan_path == 2, "stream scan was expected to be selected"
+    elif case not in DFA_EXCEPT:
+        # every reference-generated golden, wiki_annealed (125 k trie nodes) and random_utf8 included
+        assert info.dfa_active == 1 and info.scan_path == 2, "the automaton scan was expected to serve the evaluation"
 
 
 @pytest.mark.parametrize("case", [c for c in O.golden_cases() if "ids" in O.load_golden(c)["expected"]])

@@ -1,0 +1,431 @@
+// dfa.cpp -- see dfa.h.  Host code only.
+#include "dfa.h"
+
+#include <algorithm>
+#include <cstddef>
+#include <cstring>
+#include <numeric>
+
+#include "trie.h"
+
+namespace tokscore {
+
+namespace {
+inline uint8_t ascii_lower(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; } // SolutionFile.cpp:87-88
+
+struct Entry {
+	uint32_t target; // state
+	uint32_t arr;    // event emitted on arrival (virtual entries), kEvNone for a real edge
+	uint8_t code;
+	uint8_t virt;
+};
+} // namespace
+
+double DfaImage::hot_fraction(uint32_t n) const {
+	if (sample_steps == 0 || sample_slot_hits.empty()) return 1.0;
+	uint64_t s = 0;
+	const size_t m = std::min<size_t>(n, sample_slot_hits.size());
+	for (size_t i = 0; i < m; i++) s += sample_slot_hits[i];
+	return (double)s / (double)sample_steps;
+}
+
+void DfaImage::event_ids(uint32_t ev, std::vector<uint32_t> *out) const {
+	if (ev == kEvNone) return;
+	if (!(ev & kEvList)) {
+		out->push_back(ev);
+		return;
+	}
+	const uint32_t o = ev & ~kEvList;
+	for (uint32_t i = 0; i < pool[o]; i++) out->push_back(pool[o + 1 + i]);
+}
+
+bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why) const {
+	out->valid = false;
+	auto fail = [&](const char *msg) {
+		if (why) *why = msg;
+		return false;
+	};
+	const uint32_t N = (uint32_t)first_child_.size();
+	if (N == 0) return fail("no vocabulary");
+	// ---- codes: 0 = separator, 1 .. k = the bytes that label an edge, k + 1 = every other byte ----
+	bool is_label[256] = {};
+	for (const Edge &e : edges_) is_label[e.byte] = true;
+	is_label[0] = false; // documents hold no NUL (DataFile.cpp:27-29): such edges can never be followed
+	uint32_t k = 0;
+	for (uint32_t b = 1; b < 256; b++) k += is_label[b] ? 1 : 0;
+	const uint32_t ncodes = k + 2;
+	if (ncodes > DfaImage::kMaxCodes) return fail("too many distinct edge bytes");
+	const uint32_t other = k + 1;
+	{
+		uint32_t next = 1;
+		out->code[0] = 0;
+		for (uint32_t b = 1; b < 256; b++) out->code[b] = (uint8_t)(is_label[b] ? next++ : other);
+	}
+	const uint8_t *code = out->code;
+	// ---- states: the trie nodes of depth >= 1 that can be reached, and a stand-in for every code
+	// without a root child (the separator, "other", bytes that only occur inside tokens) ----
+	const uint32_t ROOT = 0;
+	const uint32_t S = N + ncodes; // state ids: [1, N) nodes, N + c stand-in of code c
+	std::vector<uint32_t> par(N, 0);
+	std::vector<uint8_t> pbyte(N, 0), reach(N, 0);
+	reach[0] = 1;
+	for (uint32_t n = 0; n < N; n++) {
+		const Edge *e = edges_.data() + first_child_[n];
+		for (uint32_t i = 0; i < n_children_[n]; i++) {
+			par[e[i].child] = n;
+			pbyte[e[i].child] = e[i].byte;
+			if (reach[n] && e[i].byte != 0) reach[e[i].child] = 1;
+		}
+	}
+	std::vector<uint32_t> d1(ncodes);
+	for (uint32_t c = 0; c < ncodes; c++) d1[c] = N + c;
+	for (uint32_t b = 1; b < 256; b++)
+		if (is_label[b] && root_child_[b]) d1[code[b]] = root_child_[b];
+	const uint32_t unknown = (uint32_t)(V_ + 2);
+	auto id_end = [&](uint32_t s) -> uint32_t { // 0 = no token ends here
+		if (s >= N) return s == N ? 0u : unknown; // the separator counts for nothing
+		const uint32_t id = ActiveId(s);
+		return id ? id : (depth_[s] == 1 ? unknown : 0u);
+	};
+	auto child = [&](uint32_t s, uint8_t b) -> uint32_t { return (s < N && b != 0) ? Child(s, b) : 0u; };
+	// ---- F, f: what falling off at a state decides ----
+	std::vector<uint32_t> f(S, ROOT), le(N, 0);
+	std::vector<uint32_t> F_off(S + 1, 0), F_dat;
+	F_dat.reserve(S + S / 4);
+	std::vector<uint8_t> str;
+	auto F_append = [&](uint32_t s, std::vector<uint32_t> *to) {
+		for (uint32_t i = F_off[s]; i < F_off[s + 1]; i++) to->push_back(F_dat[i]);
+	};
+	std::vector<uint32_t> pops;
+	// nodes are numbered breadth-first: everything a node's walk below meets is shallower and done.
+	// F lists are appended in state order, so the stand-ins (state ids >= N) are done first in a
+	// scratch copy and appended after the nodes.
+	std::vector<std::vector<uint32_t>> F_stand(ncodes);
+	for (uint32_t c = 0; c < ncodes; c++)
+		if (id_end(N + c)) F_stand[c].push_back(id_end(N + c));
+	auto F_of = [&](uint32_t s, std::vector<uint32_t> *to) {
+		if (s >= N) to->insert(to->end(), F_stand[s - N].begin(), F_stand[s - N].end());
+		else F_append(s, to);
+	};
+	auto delta = [&](uint32_t st, uint8_t b, std::vector<uint32_t> *emit) -> uint32_t {
+		for (;;) {
+			if (st == ROOT) return d1[code[b]];
+			const uint32_t ch = child(st, b);
+			if (ch) return ch;
+			F_of(st, emit);
+			st = f[st];
+		}
+	};
+	for (uint32_t n = 1; n < N; n++) {
+		F_off[n] = (uint32_t)F_dat.size();
+		if (!reach[n]) continue;
+		const uint32_t d = depth_[n];
+		le[n] = id_end(n) ? n : le[par[n]];
+		if (d == 1) {
+			F_dat.push_back(id_end(n));
+			continue;
+		}
+		str.resize(d);
+		for (uint32_t x = n, i = d; x != 0; x = par[x]) str[--i] = pbyte[x];
+		pops.clear();
+		pops.push_back(id_end(le[n]));
+		uint32_t st = ROOT;
+		for (uint32_t i = depth_[le[n]]; i < d; i++) st = delta(st, str[i], &pops);
+		f[n] = st;
+		F_dat.insert(F_dat.end(), pops.begin(), pops.end());
+	}
+	F_off[N] = (uint32_t)F_dat.size();
+	for (uint32_t c = 0; c < ncodes; c++) {
+		F_dat.insert(F_dat.end(), F_stand[c].begin(), F_stand[c].end());
+		F_off[N + c + 1] = (uint32_t)F_dat.size();
+	}
+	// ---- events ----
+	out->pool.clear();
+	uint32_t max_events = 1;
+	auto encode = [&](const std::vector<uint32_t> &ids) -> uint32_t {
+		if (ids.empty()) return DfaImage::kEvNone;
+		if (ids.size() == 1) return ids[0];
+		max_events = std::max<uint32_t>(max_events, (uint32_t)ids.size());
+		const uint32_t o = (uint32_t)out->pool.size();
+		out->pool.push_back((uint32_t)ids.size());
+		out->pool.insert(out->pool.end(), ids.begin(), ids.end());
+		return DfaImage::kEvList | o;
+	};
+	// M(s) = F(s) ++ M(f(s)): everything emitted when the whole chain is followed to the root
+	std::vector<uint32_t> M(S, DfaImage::kEvNone);
+	{
+		std::vector<uint32_t> ids;
+		auto chain_ids = [&](uint32_t s) {
+			ids.clear();
+			for (uint32_t x = s; x != ROOT; x = f[x]) F_of(x, &ids);
+		};
+		for (uint32_t s = 1; s < S; s++) {
+			if (s < N && !reach[s]) continue;
+			chain_ids(s);
+			M[s] = encode(ids);
+		}
+	}
+	// ---- rows: real children, then the virtual entries of f's chain ----
+	std::vector<uint64_t> row_off(S + 1, 0);
+	std::vector<Entry> ent;
+	{
+		std::vector<uint32_t> acc;
+		uint8_t seen[256];
+		uint64_t budget = opt.max_slots + (uint64_t)ncodes * ncodes;
+		for (uint32_t s = 1; s < S; s++) {
+			row_off[s] = ent.size();
+			if (s >= N || !reach[s]) continue;
+			memset(seen, 0, sizeof seen);
+			const Edge *e = edges_.data() + first_child_[s];
+			for (uint32_t i = 0; i < n_children_[s]; i++) {
+				if (e[i].byte == 0) continue;
+				seen[e[i].byte] = 1;
+				ent.push_back(Entry{e[i].child, DfaImage::kEvNone, code[e[i].byte], 0});
+			}
+			if (f[s] != ROOT) {
+				acc.clear();
+				F_of(s, &acc);
+				uint32_t arr_ev = 0;
+				bool arr_done = false;
+				for (uint32_t v = f[s]; v != ROOT; v = f[v]) {
+					if (v < N) {
+						const Edge *ve = edges_.data() + first_child_[v];
+						for (uint32_t i = 0; i < n_children_[v]; i++) {
+							const uint8_t b = ve[i].byte;
+							if (b == 0 || seen[b]) continue;
+							seen[b] = 1;
+							if (!arr_done) arr_ev = encode(acc), arr_done = true;
+							ent.push_back(Entry{ve[i].child, arr_ev, code[b], 1});
+						}
+					}
+					F_of(v, &acc);
+					arr_done = false;
+				}
+			}
+			if (ent.size() > budget) return fail("the automaton needs more slots than the limit");
+			std::sort(ent.begin() + (std::ptrdiff_t)row_off[s], ent.end(), [](const Entry &a, const Entry &b) { return a.code < b.code; });
+		}
+		row_off[S] = ent.size();
+	}
+	auto row_find = [&](uint32_t s, uint8_t c) -> int64_t {
+		uint64_t lo = row_off[s], hi = row_off[s + 1];
+		while (lo < hi) {
+			const uint64_t mid = (lo + hi) >> 1;
+			if (ent[mid].code < c) lo = mid + 1;
+			else hi = mid;
+		}
+		return (lo < row_off[s + 1] && ent[lo].code == c) ? (int64_t)lo : -1;
+	};
+	// ---- hotness: the sample run through the automaton (document boundaries ignored: layout only) ----
+	std::vector<uint64_t> w_row(S, 0);
+	std::vector<uint32_t> w_ent(ent.size(), 0), w_d1(ncodes, 0);
+	out->sample_steps = out->sample_virtual = out->sample_miss = 0;
+	if (opt.sample && opt.sample_bytes) {
+		uint32_t st = d1[0];
+		for (uint64_t i = 0; i < opt.sample_bytes; i++) {
+			const uint8_t c = code[ascii_lower(opt.sample[i])];
+			out->sample_steps++;
+			if (st == d1[0]) { // the root row (after a separator): every code is there
+				w_d1[c]++;
+				st = d1[c];
+				continue;
+			}
+			w_row[st]++;
+			const int64_t j = row_find(st, c);
+			if (j >= 0) {
+				w_ent[j]++;
+				out->sample_virtual += ent[j].virt;
+				st = ent[j].target;
+			} else {
+				out->sample_miss++;
+				w_d1[c]++;
+				st = d1[c];
+			}
+		}
+	}
+	// ---- placement ----
+	std::vector<uint8_t> used(4096, 0), base_used(4096, 0);
+	std::vector<uint32_t> next_free(4096);
+	for (uint32_t i = 0; i < 4096; i++) next_free[i] = i;
+	auto ensure = [&](uint64_t n) {
+		if (used.size() < n) {
+			const uint64_t old = used.size(), m = std::max<uint64_t>(n, old * 2);
+			used.resize(m, 0);
+			base_used.resize(m, 0);
+			next_free.resize(m);
+			for (uint64_t i = old; i < m; i++) next_free[i] = (uint32_t)i;
+		}
+	};
+	auto find_free = [&](uint64_t s) -> uint64_t {
+		ensure(s + 1);
+		uint64_t r = s;
+		while (next_free[r] != r) {
+			r = next_free[r];
+			ensure(r + 1);
+		}
+		while (next_free[s] != r) {
+			const uint64_t t = next_free[s];
+			next_free[s] = (uint32_t)r;
+			s = t;
+		}
+		return r;
+	};
+	uint64_t max_used = 0, max_base = 0;
+	auto take = [&](uint64_t slot) {
+		ensure(slot + 2);
+		used[slot] = 1;
+		next_free[slot] = (uint32_t)(slot + 1);
+		max_used = std::max(max_used, slot);
+	};
+	std::vector<uint32_t> base(S, 0);
+	// the root row: dense at base 0, slot c = the depth-1 state of code c
+	for (uint32_t c = 0; c < ncodes; c++) take(c);
+	// depth-1 rows at c * stride: the smallest stride whose occupied slots are all different and clear of the root row
+	uint32_t stride = 0;
+	{
+		std::vector<uint8_t> tmp;
+		for (uint32_t s = 1; s <= ncodes && !stride; s++) {
+			tmp.assign((size_t)ncodes * s + ncodes + 1, 0);
+			bool ok = true;
+			for (uint32_t c = 1; c < ncodes && ok; c++)
+				for (uint64_t j = row_off[d1[c]]; j < row_off[d1[c] + 1] && ok; j++) {
+					const uint32_t t = c * s + ent[j].code;
+					ok = t >= ncodes && !tmp[t];
+					tmp[t] = 1;
+				}
+			if (ok) stride = s;
+		}
+		if (!stride) stride = ncodes; // (always fits: rows then do not overlap at all)
+	}
+	ensure((uint64_t)ncodes * stride + ncodes + 2);
+	for (uint32_t c = 0; c < ncodes; c++) {
+		base[d1[c]] = c * stride;
+		base_used[c * stride] = 1;
+		max_base = std::max<uint64_t>(max_base, c * stride);
+		if (c == 0) continue;
+		for (uint64_t j = row_off[d1[c]]; j < row_off[d1[c] + 1]; j++) take(c * stride + ent[j].code);
+	}
+	// the base of states without a row: a value no state has, so no slot "belongs" to it
+	uint32_t empty_base = 1;
+	while (base_used[empty_base]) empty_base++, ensure(empty_base + 1);
+	base_used[empty_base] = 1;
+	max_base = std::max<uint64_t>(max_base, empty_base);
+	// every other row, the busiest first
+	std::vector<uint32_t> order;
+	{
+		std::vector<uint8_t> is_d1(S, 0);
+		for (uint32_t c = 0; c < ncodes; c++) is_d1[d1[c]] = 1;
+		for (uint32_t s = 1; s < S; s++) {
+			if (is_d1[s]) continue;
+			if (row_off[s + 1] == row_off[s]) {
+				base[s] = empty_base;
+				continue;
+			}
+			order.push_back(s);
+		}
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w_row[a] > w_row[b]; });
+	}
+	const uint64_t slot_limit = std::min<uint64_t>(opt.max_slots, DfaImage::kMaxSlots);
+	for (uint32_t s : order) {
+		const Entry *e = ent.data() + row_off[s];
+		const uint32_t nc = (uint32_t)(row_off[s + 1] - row_off[s]);
+		const uint32_t c0 = e[0].code;
+		uint64_t t = find_free(std::max<uint64_t>(1, (uint64_t)c0 + 1));
+		uint64_t b = 0;
+		for (uint32_t tries = 0;; tries++) {
+			b = t - c0;
+			ensure(b + ncodes + 1);
+			bool ok = !base_used[b];
+			for (uint32_t i = 0; ok && i < nc; i++) ok = !used[b + e[i].code];
+			if (ok) break;
+			if (tries >= 512) { // (deep vocabularies: see VocabTrie::Pack)
+				for (b = max_base + 1;; b++) {
+					ensure(b + ncodes + 1);
+					bool fits = true;
+					for (uint32_t i = 0; fits && i < nc; i++) fits = !used[b + e[i].code];
+					if (fits) break;
+				}
+				break;
+			}
+			t = find_free(t + 1);
+		}
+		base_used[b] = 1;
+		max_base = std::max(max_base, b);
+		base[s] = (uint32_t)b;
+		for (uint32_t i = 0; i < nc; i++) take(b + e[i].code);
+		if (max_used + ncodes + 1 > slot_limit) return fail("the automaton needs more slots than the limit");
+	}
+	const uint64_t nslots = std::max(max_used + 1, max_base + ncodes + 1); // base + any code is a readable slot
+	if (nslots > slot_limit) return fail("the automaton needs more slots than the limit");
+	// ---- the image ----
+	out->ncodes = ncodes;
+	out->stride = stride;
+	out->nslots = (uint32_t)nslots;
+	out->slot.assign(nslots, DfaImage::kEmptyWord);
+	out->ev_miss.assign(nslots, DfaImage::kEvNone);
+	out->ev_arr.assign(nslots, DfaImage::kEvNone);
+	out->sample_slot_hits.assign(nslots, 0);
+	out->real_slots = out->virtual_slots = 0;
+	for (uint32_t c = 0; c < ncodes; c++) {
+		out->slot[c] = c << DfaImage::kLabelShift | base[d1[c]];
+		out->ev_miss[c] = M[d1[c]];
+		out->sample_slot_hits[c] = w_d1[c];
+		out->real_slots++;
+	}
+	for (uint32_t s = 1; s < S; s++) {
+		for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) {
+			const Entry &e = ent[j];
+			const uint32_t t = base[s] + e.code;
+			out->slot[t] = (uint32_t)e.code << DfaImage::kLabelShift | (e.virt ? DfaImage::kArr : 0u) | base[e.target];
+			out->ev_miss[t] = M[e.target];
+			out->ev_arr[t] = e.arr;
+			out->sample_slot_hits[t] = w_ent[j];
+			if (e.virt) out->virtual_slots++;
+			else out->real_slots++;
+		}
+	}
+	out->max_events = max_events;
+	out->valid = true;
+	return true;
+}
+
+void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t V, uint64_t *counts,
+            uint64_t *total_tokens) {
+	for (uint64_t i = 0; i < V + 3; i++) counts[i] = 0;
+	*total_tokens = 0;
+	std::vector<uint64_t> n_miss(img.nslots, 0), n_arr(img.nslots, 0);
+	uint32_t S = img.start_word(), U = 0;
+	for (uint64_t d = 0; d < D; d++) {
+		for (uint64_t p = off[d]; p <= off[d + 1]; p++) {
+			const uint32_t c = p < off[d + 1] ? img.code[ascii_lower(bytes[p])] : 0u;
+			const uint32_t t = (S & DfaImage::kBaseMask) + c;
+			const uint32_t x = img.slot[t];
+			if ((x >> DfaImage::kLabelShift) == c) {
+				if (x & DfaImage::kArr) n_arr[t]++;
+				S = x;
+				U = t;
+			} else {
+				n_miss[U]++;
+				S = c * img.stride;
+				U = c;
+			}
+		}
+	}
+	// (the run ends in the separator's state: nothing is pending)
+	std::vector<uint32_t> ids;
+	for (uint32_t t = 0; t < img.nslots; t++) {
+		for (int kind = 0; kind < 2; kind++) {
+			const uint64_t n = kind ? n_arr[t] : n_miss[t];
+			if (!n) continue;
+			ids.clear();
+			img.event_ids(kind ? img.ev_arr[t] : img.ev_miss[t], &ids);
+			for (uint32_t id : ids) {
+				counts[id] += n;
+				*total_tokens += n;
+			}
+		}
+	}
+	counts[0] = counts[1] = D; // START / END once per document (SolutionFile.cpp:85,98)
+}
+
+} // namespace tokscore

@@ -1,0 +1,84 @@
+// dfa.h -- the vocabulary as a "one transition per corpus byte" automaton (round 3).
+//
+// SolutionFile::Tokenize (/root/reference/src/files/SolutionFile.cpp:89-97) probes
+// len = min(max_len_, remaining) .. 1 at every token start: a trie walk that goes as deep as the
+// bytes allow, falls back to the longest token end it passed and starts again behind it.  The
+// bytes between that token end and the point where the walk fell off are looked at twice (1.15
+// lookups per byte on the bench vocabulary, 2.7 - 3.4 on the vocabulary the reference's own annealer
+// writes, tests/golden/wiki_annealed, whose prefixes are mostly not tokens).  This image removes the
+// second look: a state is a trie node s ("the bytes since the last decided token end spell s"), and
+// for every state the builder works out, once, what falling off at s means --
+//   F(s)  the tokens that are decided at that moment: the longest token end on s's path, then the
+//         greedy tokens of what is left for as long as they are decided too, and
+//   f(s)  the node spelled by the undecided rest (always a trie path),
+// so that the transition on byte c is child(s, c) if it exists and otherwise the transition of f(s),
+// with F(s) emitted -- the construction of LinMaxMatch (Song et al., "Fast WordPiece Tokenization",
+// EMNLP 2021) applied to the reference's rule set: bytes, not code points; every byte is a token of
+// its own or UNKNOWN (SolutionFile.cpp:92-94), so the chain of f always ends at the root.  The scan
+// kernel (kernels_dfa.hip) wants exactly ONE slot read per byte, so the chain is flattened:
+//   * a miss in s's row means "all of f's chain emitted, next state = the depth-1 state of c", and
+//     the depth-1 states' rows sit at base c * stride, so that state needs no read at all;
+//   * a byte c for which some state on f's chain does have a child gets a VIRTUAL slot in s's own
+//     row (flagged kArr) that leads to that child's row and stands for the tokens emitted on the way.
+// Token counts come from events, not from ids: the kernel logs the slot whose state it left by a miss
+// (ev_miss[slot] = every token of the chain) and the virtual slot it arrived on (ev_arr[slot]); the
+// histogram over slots is turned into counts[id] with these tables at the end of an evaluation.
+// Slots are ordered hot-first (a 2 MB sample of the corpus run through the automaton): the first
+// `lds_slots` live in LDS, the rest is read from L2.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace tokscore {
+
+struct DfaImage {
+	// slot word: label (code) : 8 | kArr : 1 | base : 23.  The state a slot stands for looks its next
+	// byte up at slot base + code.  Empty slots carry label 0xFF, which no code equals.
+	static constexpr uint32_t kLabelShift = 24;
+	static constexpr uint32_t kArr = 0x800000u;
+	static constexpr uint32_t kBaseMask = 0x7FFFFFu;
+	static constexpr uint32_t kEmptyWord = 0xFF000000u;
+	static constexpr uint32_t kMaxCodes = 254;      // codes 0 .. ncodes - 1 < 255
+	static constexpr uint64_t kMaxSlots = 1u << 23;
+	// events: kEvNone = nothing to count, id < 2^31 = one token id, kEvList | o = pool[o] ids at pool[o + 1 ..]
+	static constexpr uint32_t kEvNone = 0xFFFFFFFFu;
+	static constexpr uint32_t kEvList = 0x80000000u;
+
+	std::vector<uint32_t> slot;
+	std::vector<uint32_t> ev_miss; // per slot: what leaving its state by a miss emits
+	std::vector<uint32_t> ev_arr;  // per slot: what arriving on it emits (kArr slots only)
+	std::vector<uint32_t> pool;
+	uint8_t code[256] = {};
+	uint32_t ncodes = 0;  // code 0 = document separator, ncodes - 1 = every byte that labels no edge
+	uint32_t stride = 0;  // the row of the depth-1 state of code c starts at slot c * stride (row 0 = the root's)
+	uint32_t nslots = 0;
+	uint32_t real_slots = 0, virtual_slots = 0;
+	uint32_t max_events = 0; // longest event list
+	// what the hotness sample saw (layout only, never results)
+	uint64_t sample_steps = 0, sample_virtual = 0, sample_miss = 0;
+	bool valid = false;
+
+	// the state after a document separator: slot 0 (the root row is the separator's row)
+	uint32_t start_word() const { return slot.empty() ? 0u : slot[0]; }
+	// fraction of the sample's lookups that fall on slots [0, n)
+	std::vector<uint32_t> sample_slot_hits; // per slot, for hot_fraction
+	double hot_fraction(uint32_t n) const;
+	// appends an event's ids to out (with repetitions)
+	void event_ids(uint32_t ev, std::vector<uint32_t> *out) const;
+};
+
+struct DfaOptions {
+	uint64_t max_slots = 6u << 20; // give up above this many slots (virtual slots of deep vocabularies run into tens of millions)
+	const uint8_t *sample = nullptr; // raw corpus bytes for the hot-first order (lower-cased here)
+	uint64_t sample_bytes = 0;
+};
+
+// Host-side check of an image (CPU tests of the builder; never used by a scoring entry point): runs
+// the automaton over documents exactly as the kernel does -- codes of the lower-cased bytes, a
+// separator after every document -- and adds up counts[V + 3] and total_tokens from the events.
+void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t V, uint64_t *counts,
+            uint64_t *total_tokens);
+
+} // namespace tokscore

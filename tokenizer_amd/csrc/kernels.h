@@ -218,6 +218,55 @@ void launch_fixup_stream(const StreamTrieDev &T, const uint32_t *slot_id, const 
                          uint32_t *changed, uint32_t epoch, unsigned long long *out, uint32_t total_index, hipStream_t stream);
 uint64_t stream_scan_capacity_batches(uint64_t prep_total, uint32_t waves_total);
 
+// as launch_histogram_slots, for the event streams of the automaton scan (kernels_dfa.hip): ev[s] is an
+// event (dfa.h: an id, kEvNone, or a list in `pool`); out[total_index] += the tokens the events stand for
+void launch_histogram_events(const StreamDev &Q, uint32_t nslots, const uint32_t *ev, const uint32_t *pool,
+                             unsigned long long *out, uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream);
+
+// kernels_dfa.hip -- full evaluation on the one-transition-per-byte automaton (dfa.h)
+struct DfaDev {
+	const uint32_t *slot;    // [nslots, padded to 16 bytes] label : 8 | kArr : 1 | base : 23
+	const uint32_t *ev_miss; // [nslots] event of leaving the slot's state by a miss
+	const uint32_t *ev_arr;  // [nslots] event of arriving on a virtual slot
+	const uint32_t *pool;    // event lists
+	uint32_t nslots;
+	uint32_t lds_slots;      // slots [0, lds_slots) are staged in LDS; events on them go to the streams
+	uint32_t stride;         // the depth-1 state of code c has its row at c * stride
+};
+struct DfaWork {
+	const uint2 *tcodes;     // the ranges' codes transposed (kernels_dfa.hip: dfa_transpose_kernel)
+	uint32_t range_bytes;    // multiple of 8
+	uint32_t nranges;        // nwb * 64 * chains
+	uint32_t nwb;            // wave blocks: 64 lanes x `chains` ranges each
+	uint2 *entry;            // [nranges] state (base | kArr, event slot) the range's count starts from
+	uint2 *exit_a;           // [nranges] state the scan ended the range in
+	uint2 *exit_b;           // [nranges] ... after the fix-up, where exit_tag[g] == the evaluation's epoch
+	uint32_t *exit_tag;
+	uint32_t *cold_miss;     // [nslots - lds_slots] events on slots beyond the LDS prefix (zero between evaluations)
+	uint32_t *cold_arr;
+};
+struct DfaScanPlan {
+	uint32_t blocks, waves_per_block, chains;
+	uint32_t lds_slots, lds_bytes;
+	uint32_t range_bytes, nwb;
+};
+// lds_cap: 0, or fewer LDS slots than fit (tests: exercises the lookups and events beyond the prefix)
+bool plan_dfa_scan(uint32_t nslots, uint64_t prep_total, uint32_t num_cus, uint32_t chains_hint, uint32_t lds_cap, DfaScanPlan *plan);
+uint32_t dfa_lds_slots_max(uint32_t lds_cap);
+uint64_t dfa_stream_capacity_batches(const DfaScanPlan &plan);
+void launch_dfa_transpose(const uint8_t *prep, uint64_t prep_total, uint32_t range_bytes, uint32_t chains, uint64_t nwb,
+                          void *tcodes, hipStream_t stream);
+void launch_dfa_reset_states(const DfaWork &W, uint32_t start_word, hipStream_t stream);
+// clears out (when given) and presets START / END / total_bytes; both streams' cursors = first_batches; changed[0..1] = 0
+void launch_dfa_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, const StreamDev &Qm,
+                        const StreamDev &Qa, uint32_t first_batches, uint32_t *changed, hipStream_t stream);
+void launch_dfa_scan(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, const StreamDev &Qa, const DfaScanPlan &plan,
+                     hipStream_t stream, const OutInit &init = OutInit{}, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+// codes: the prepared corpus (linear), readable up to nranges * range_bytes; changed: two words, zero on entry
+void launch_dfa_fixup(const DfaDev &A, const DfaWork &W, const uint8_t *codes, uint32_t *changed, uint32_t epoch,
+                      unsigned long long *out, uint32_t total_index, hipStream_t stream);
+void launch_dfa_cold_reduce(const DfaDev &A, const DfaWork &W, unsigned long long *out, uint32_t total_index, hipStream_t stream);
+
 // kernels_count.hip -- closed-vocabulary all-occurrence counting (GetTokens.cpp:21-27)
 struct CountPlan {
 	uint32_t halo;      // bytes staged past a tile (longest walk + slack)

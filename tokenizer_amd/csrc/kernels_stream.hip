@@ -1702,11 +1702,17 @@ __device__ void fixup_ordered_pass(const FixDev &F) {
 // a slot's count goes to the id the slot counts for; entries on slots nobody counts (document
 // separators) leave the token total again (main.cpp:41 counts the ids Tokenize returned, not the
 // separators this layout adds).  No map: counts per slot.
+// pool != nullptr: slot_id[] holds events of the automaton scan (dfa.h): an id with the top bit set is a
+// list of ids in pool, each of which the entry counts for (the entry itself was added to the total once)
 __device__ __forceinline__ void book_slot(uint32_t s, long long sum, const uint32_t *slot_id, unsigned long long *out,
-                                          uint32_t total_index) {
+                                          uint32_t total_index, const uint32_t *pool = nullptr) {
 	const uint32_t id = slot_id ? slot_id[s] : s;
 	if (id == 0xFFFFFFFFu) atomicAdd(&out[total_index], (unsigned long long)(-sum));
-	else atomicAdd(&out[id], (unsigned long long)sum);
+	else if (pool && (id & 0x80000000u)) {
+		const uint32_t o = id & 0x7FFFFFFFu, len = pool[o];
+		for (uint32_t i = 0; i < len; i++) atomicAdd(&out[pool[o + 1 + i]], (unsigned long long)sum);
+		atomicAdd(&out[total_index], (unsigned long long)(sum * ((long long)len - 1)));
+	} else atomicAdd(&out[id], (unsigned long long)sum);
 }
 __host__ __device__ __forceinline__ uint32_t slab_row_stride(uint32_t nslots) { return (nslots + 1) & ~1u; } // int16 units
 
@@ -1721,7 +1727,7 @@ __host__ __device__ __forceinline__ uint32_t slab_row_stride(uint32_t nslots) { 
 template <bool ONE_RANGE>
 __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t nslots, uint32_t range_slots, int16_t *slab,
                                                           uint32_t flip, const uint32_t *slot_id, unsigned long long *out,
-                                                          uint32_t total_index, FixDev F) {
+                                                          uint32_t total_index, FixDev F, const uint32_t *pool) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char hist_smem[];
 	uint32_t *bins = reinterpret_cast<uint32_t *>(hist_smem);
 	__shared__ int s_total;
@@ -1818,7 +1824,7 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 		const int v = (int)bins[i];
 		const bool fits = v >= -32768 && v <= 32767;
 		row[lo + i] = fits ? (int16_t)v : (int16_t)0;
-		if (!fits) book_slot(lo + i, (long long)v, slot_id, out, total_index);
+		if (!fits) book_slot(lo + i, (long long)v, slot_id, out, total_index, pool);
 	}
 	__syncthreads();
 	if (blockIdx.y == 0 && threadIdx.x == 0 && s_total != 0) atomicAdd(&out[total_index], (unsigned long long)(long long)s_total);
@@ -1832,7 +1838,8 @@ __global__ void __launch_bounds__(1024) hist_slots_kernel(StreamDev Qd, uint32_t
 constexpr uint32_t kMapReduceGroups = 16;
 __global__ void __launch_bounds__(1024) slab_reduce_map_kernel(const int16_t *slab, uint32_t rows, uint32_t nslots,
                                                                const uint32_t *slot_id, unsigned long long *out,
-                                                               uint32_t total_index, uint32_t *cursor, uint32_t next_first_batches) {
+                                                               uint32_t total_index, uint32_t *cursor, uint32_t next_first_batches,
+                                                               const uint32_t *pool) {
 	__shared__ int part[kMapReduceGroups][64][2];
 	// (the histogram has read cursor[0], the fix-up is done with its two words: ready for the next evaluation)
 	if (next_first_batches != 0 && blockIdx.x == 0 && threadIdx.x == 0) cursor[0] = next_first_batches, cursor[2] = 0u, cursor[3] = 0u;
@@ -1862,8 +1869,8 @@ __global__ void __launch_bounds__(1024) slab_reduce_map_kernel(const int16_t *sl
 	__syncthreads();
 	if (grp != 0 || s >= nslots) return;
 	for (uint32_t g = 1; g < kMapReduceGroups; g++) lo += part[g][lane][0], hi += part[g][lane][1];
-	if (lo != 0) book_slot(s, lo, slot_id, out, total_index);
-	if (hi != 0 && s + 1 < nslots) book_slot(s + 1, hi, slot_id, out, total_index);
+	if (lo != 0) book_slot(s, lo, slot_id, out, total_index, pool);
+	if (hi != 0 && s + 1 < nslots) book_slot(s + 1, hi, slot_id, out, total_index, pool);
 }
 
 } // namespace
@@ -2102,7 +2109,7 @@ void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const Stre
 namespace {
 void histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
                      uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip, FixDev F,
-                     uint32_t next_first_batches = 0) {
+                     uint32_t next_first_batches = 0, const uint32_t *pool = nullptr) {
 	constexpr uint32_t kMaxRange = 40000;
 	const uint32_t ranges = (nslots + kMaxRange - 1) / kMaxRange;
 	const uint32_t range = (nslots + ranges - 1) / ranges;
@@ -2111,19 +2118,24 @@ void histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_i
 	auto go = [&](auto kernel) {
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		hipLaunchKernelGGL(kernel, dim3(slab_blocks, ranges), dim3(1024), lds, stream, Q, nslots, range, rows, flip ? 1u : 0u,
-		                   slot_id, out, total_index, F);
+		                   slot_id, out, total_index, F, pool);
 	};
 	if (F.blocks > slab_blocks) F.blocks = slab_blocks;
 	if (ranges == 1) go(&hist_slots_kernel<true>);
 	else go(&hist_slots_kernel<false>);
 	hipLaunchKernelGGL(slab_reduce_map_kernel, dim3((nslots + 127) / 128), dim3(64 * kMapReduceGroups), 0, stream, rows,
-	                   slab_blocks, nslots, slot_id, out, total_index, Q.cursor, next_first_batches);
+	                   slab_blocks, nslots, slot_id, out, total_index, Q.cursor, next_first_batches, pool);
 }
 } // namespace
 
 void launch_histogram_slots(const StreamDev &Q, uint32_t nslots, const uint32_t *slot_id, unsigned long long *out,
                             uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream, bool flip) {
 	histogram_slots(Q, nslots, slot_id, out, total_index, slab, slab_blocks, stream, flip, FixDev{});
+}
+
+void launch_histogram_events(const StreamDev &Q, uint32_t nslots, const uint32_t *ev, const uint32_t *pool,
+                             unsigned long long *out, uint32_t total_index, uint32_t *slab, uint32_t slab_blocks, hipStream_t stream) {
+	histogram_slots(Q, nslots, ev, out, total_index, slab, slab_blocks, stream, false, FixDev{}, 0, pool);
 }
 
 // A full evaluation's last two steps in one launch: the fix-up of the ranges (launch_fixup_stream) by

@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 
+#include "dfa.h"
 #include "kernels.h"
 #include "trie.h"
 
@@ -220,6 +221,34 @@ struct tokscore_ctx {
 	uint8_t *h_patch_lt = nullptr;    // pinned, beside h_patch
 	uint32_t *h_patch_id = nullptr;
 
+	// automaton scan (kernels_dfa.hip, dfa.h): serves full evaluations while the image matches the
+	// vocabulary; built with the plan, rebuilt after toggles once two full evaluations in a row found it stale
+	DfaImage dimg;
+	int dfa_state = 0;             // 0 not tried for this plan, 1 ready, -1 not available
+	uint64_t toggle_version = 0;   // counts tokscore_toggle calls that changed something
+	uint64_t dfa_version = 0;      // toggle_version the device image was built from
+	uint32_t dfa_stale_evals = 0;
+	bool dfa_enabled = true;       // TOKSCORE_DFA=0 switches it off
+	uint64_t dfa_max_slots = 6u << 20;
+	uint32_t dfa_chains = 0;
+	uint32_t dfa_lds_cap = 0;
+	DfaScanPlan dplan = {};
+	uint32_t *d_dslot = nullptr, *d_dev_miss = nullptr, *d_dev_arr = nullptr, *d_dpool = nullptr;
+	uint8_t *d_dcodes = nullptr;   // the prepared corpus in the automaton's codes, linear
+	void *d_dtcodes = nullptr;     // ... transposed for the scan
+	uint2 *d_dstate = nullptr;     // entry | exit_a | exit_b
+	uint32_t *d_dtag = nullptr;
+	uint32_t *d_dcold = nullptr;   // miss | arrival counters of the slots beyond the LDS prefix
+	void *d_dstream_m = nullptr, *d_dstream_a = nullptr;
+	uint32_t *d_dfill_m = nullptr, *d_dfill_a = nullptr;
+	uint32_t *d_dcursor = nullptr; // [0..1] miss stream, [4..5] arrival stream, [8..9] fix-up words
+	uint32_t dstream_cap = 0;
+	uint32_t *d_dslab = nullptr;
+	uint32_t dslab_blocks = 0;
+	uint32_t dfa_epoch = 0;
+	bool dfa_used_last = false;    // the last full evaluation ran on the automaton scan
+	double dfa_build_ms = 0, dfa_plan_ms = 0;
+
 	// outputs
 	unsigned long long *d_out = nullptr;
 	uint64_t d_out_cap = 0;
@@ -303,10 +332,23 @@ int build_prepared(tokscore_ctx *c) {
 	return TOKSCORE_OK;
 }
 
+void free_dfa(tokscore_ctx *c) {
+	void **bufs[] = {(void **)&c->d_dslot, (void **)&c->d_dev_miss, (void **)&c->d_dev_arr, (void **)&c->d_dpool, (void **)&c->d_dcodes,
+	                 &c->d_dtcodes, (void **)&c->d_dstate, (void **)&c->d_dtag, (void **)&c->d_dcold, &c->d_dstream_m, &c->d_dstream_a,
+	                 (void **)&c->d_dfill_m, (void **)&c->d_dfill_a, (void **)&c->d_dcursor, (void **)&c->d_dslab};
+	for (void **b : bufs) {
+		if (*b) (void)hipFree(*b);
+		*b = nullptr;
+	}
+	c->dfa_state = 0;
+	c->dfa_used_last = false;
+}
+
 void free_plan(tokscore_ctx *c) {
 	// nothing enqueued by an earlier asynchronous evaluation may still use these buffers
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	if (c->side) (void)hipStreamSynchronize(c->side);
+	free_dfa(c);
 	if (c->d_chunk_begin) (void)hipFree(c->d_chunk_begin);
 	if (c->d_chunk_state) (void)hipFree(c->d_chunk_state);
 	if (c->d_chunk_first_doc) (void)hipFree(c->d_chunk_first_doc);
@@ -796,6 +838,153 @@ int ensure_plan(tokscore_ctx *c) {
 	return TOKSCORE_OK;
 }
 
+// The automaton's image (host + device) from the vocabulary as it is.  false: not available.
+bool upload_dfa_image(tokscore_ctx *c) {
+	DfaOptions opt;
+	opt.max_slots = c->dfa_max_slots;
+	opt.sample = c->sample.empty() ? nullptr : c->sample.data();
+	opt.sample_bytes = c->sample.size();
+	std::string why;
+	const auto t0 = std::chrono::steady_clock::now();
+	if (!c->trie.BuildDfa(&c->dimg, opt, &why)) return false;
+	c->dfa_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	const DfaImage &g = c->dimg;
+	const size_t n = g.nslots;
+	for (uint32_t **b : {&c->d_dslot, &c->d_dev_miss, &c->d_dev_arr, &c->d_dpool}) {
+		if (*b) (void)hipFree(*b);
+		*b = nullptr;
+	}
+	bool ok = hipMalloc((void **)&c->d_dslot, (n + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dev_miss, (n + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dev_arr, (n + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dpool, (g.pool.size() + 16) * sizeof(uint32_t)) == hipSuccess;
+	ok = ok && hipMemsetAsync(c->d_dslot + n, 0xFF, 16 * sizeof(uint32_t), c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dslot, g.slot.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dev_miss, g.ev_miss.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dev_arr, g.ev_arr.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+	     (g.pool.empty() || hipMemcpyAsync(c->d_dpool, g.pool.data(), g.pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess) &&
+	     hipStreamSynchronize(c->stream) == hipSuccess;
+	if (!ok) (void)hipGetLastError();
+	return ok;
+}
+
+DfaDev dfa_dev(const tokscore_ctx *c) {
+	DfaDev A;
+	A.slot = c->d_dslot, A.ev_miss = c->d_dev_miss, A.ev_arr = c->d_dev_arr, A.pool = c->d_dpool;
+	A.nslots = c->dimg.nslots;
+	A.lds_slots = std::min<uint32_t>(c->dplan.lds_slots, c->dimg.nslots);
+	A.stride = c->dimg.stride;
+	return A;
+}
+
+DfaWork dfa_work(const tokscore_ctx *c) {
+	DfaWork W;
+	W.tcodes = (const uint2 *)c->d_dtcodes;
+	W.range_bytes = c->dplan.range_bytes;
+	W.nwb = c->dplan.nwb;
+	W.nranges = c->dplan.nwb * 64 * c->dplan.chains;
+	W.entry = c->d_dstate;
+	W.exit_a = c->d_dstate + W.nranges;
+	W.exit_b = c->d_dstate + 2 * (size_t)W.nranges;
+	W.exit_tag = c->d_dtag;
+	W.cold_miss = c->d_dcold;
+	W.cold_arr = c->d_dcold + (c->dimg.nslots - std::min<uint32_t>(c->dplan.lds_slots, c->dimg.nslots)) + 1;
+	return W;
+}
+
+// Everything the automaton scan needs for the resident corpus and the vocabulary as it is; leaves
+// dfa_state at 1 (ready) or -1 (not for this vocabulary / corpus: the plan's scan serves every evaluation).
+void ensure_dfa(tokscore_ctx *c) {
+	if (c->dfa_state != 0) return;
+	c->dfa_state = -1;
+	const uint64_t prep_total = c->total + c->D;
+	if (!c->dfa_enabled || c->D == 0 || c->total == 0 || c->V + 5 >= 0x7FFFFFFFull || prep_total + kCorpusPad >= 0xFFFF0000ull) return;
+	const auto t0 = std::chrono::steady_clock::now();
+	if (!upload_dfa_image(c)) return;
+	DfaScanPlan &P = c->dplan;
+	if (!plan_dfa_scan(c->dimg.nslots, prep_total, (uint32_t)c->num_cus, c->dfa_chains, c->dfa_lds_cap, &P)) return;
+	const uint64_t nranges = (uint64_t)P.nwb * 64 * P.chains;
+	const uint64_t covered = nranges * P.range_bytes; // >= prep_total: the rest reads as separators
+	const uint64_t lin_bytes = std::max<uint64_t>(covered, prep_total) + kCorpusPad;
+	const uint32_t ncold = c->dimg.nslots - std::min<uint32_t>(P.lds_slots, c->dimg.nslots);
+	c->dstream_cap = 0;
+	const uint64_t cap = dfa_stream_capacity_batches(P);
+	if (cap > 0x7FFFFFF0ull) return;
+	uint32_t *d_flags = nullptr;
+	uint32_t flags = 1;
+	c->dslab_blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, c->total / (256 * 1024)));
+	bool ok = hipMalloc((void **)&c->d_dcodes, lin_bytes) == hipSuccess && hipMalloc((void **)&d_flags, sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc(&c->d_dtcodes, covered) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dstate, 3 * nranges * sizeof(uint2)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dtag, nranges * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dcold, (2 * (size_t)ncold + 2) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc(&c->d_dstream_m, cap * kStreamBatch * 1024) == hipSuccess &&
+	          hipMalloc(&c->d_dstream_a, cap * kStreamBatch * 1024) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dfill_m, cap * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dfill_a, cap * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dcursor, 16 * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dslab, (size_t)c->dslab_blocks * (P.lds_slots + 2) * sizeof(uint32_t)) == hipSuccess;
+	ok = ok && hipMemsetAsync(c->d_dcodes, 0, lin_bytes, c->stream) == hipSuccess &&
+	     hipMemsetAsync(d_flags, 0, sizeof(uint32_t), c->stream) == hipSuccess &&
+	     hipMemsetAsync(c->d_dtag, 0, nranges * sizeof(uint32_t), c->stream) == hipSuccess &&
+	     hipMemsetAsync(c->d_dcold, 0, (2 * (size_t)ncold + 2) * sizeof(uint32_t), c->stream) == hipSuccess &&
+	     hipMemsetAsync(c->d_dcursor, 0, 16 * sizeof(uint32_t), c->stream) == hipSuccess;
+	if (ok) {
+		CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
+		ByteCodes M;
+		memcpy(M.code, c->dimg.code, 256);
+		launch_prep_corpus(C, M, c->d_dcodes, prep_total, d_flags, c->stream);
+		launch_dfa_transpose(c->d_dcodes, prep_total, P.range_bytes, P.chains, P.nwb, c->d_dtcodes, c->stream);
+		launch_dfa_reset_states(dfa_work(c), c->dimg.start_word(), c->stream);
+		ok = hipMemcpyAsync(&flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+		     hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+	}
+	if (d_flags) (void)hipFree(d_flags);
+	if (!ok || flags != 0) { // (flags: a document holds a NUL byte -- the separator's code inside a document)
+		(void)hipGetLastError();
+		free_dfa(c);
+		c->dfa_state = -1;
+		return;
+	}
+	c->dstream_cap = (uint32_t)cap;
+	c->dfa_version = c->toggle_version;
+	c->dfa_stale_evals = 0;
+	c->dfa_epoch = 0;
+	c->dfa_state = 1;
+	c->dfa_plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+// After toggles: a new image for the same corpus (the codes and the ranges stay: toggles do not change
+// the trie's edges), every range's entry back to a guess.
+bool refresh_dfa(tokscore_ctx *c) {
+	(void)hipDeviceSynchronize(); // (an evaluation on a caller's stream may still read what is replaced here)
+	const uint32_t old_codes = c->dimg.ncodes;
+	if (!upload_dfa_image(c) || c->dimg.ncodes != old_codes) return false;
+	DfaScanPlan P = c->dplan;
+	const uint32_t lds = std::min<uint32_t>(dfa_lds_slots_max(c->dfa_lds_cap), c->dimg.nslots);
+	// (the cold counters and the slab are sized by the image)
+	if (c->d_dcold) (void)hipFree(c->d_dcold);
+	if (c->d_dslab) (void)hipFree(c->d_dslab);
+	c->d_dcold = nullptr, c->d_dslab = nullptr;
+	P.lds_slots = lds;
+	P.lds_bytes = ((lds + 3) & ~3u) * 4;
+	c->dplan = P;
+	const uint32_t ncold = c->dimg.nslots - lds;
+	bool ok = hipMalloc((void **)&c->d_dcold, (2 * (size_t)ncold + 2) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dslab, (size_t)c->dslab_blocks * (P.lds_slots + 2) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMemsetAsync(c->d_dcold, 0, (2 * (size_t)ncold + 2) * sizeof(uint32_t), c->stream) == hipSuccess &&
+	          hipMemsetAsync(c->d_dtag, 0, (size_t)P.nwb * 64 * P.chains * sizeof(uint32_t), c->stream) == hipSuccess;
+	if (!ok) {
+		(void)hipGetLastError();
+		return false;
+	}
+	launch_dfa_reset_states(dfa_work(c), c->dimg.start_word(), c->stream);
+	c->dfa_version = c->toggle_version;
+	c->dfa_stale_evals = 0;
+	c->dfa_epoch = 0;
+	return true;
+}
+
 int ensure_out(tokscore_ctx *c) {
 	const uint64_t n = c->V + 5;
 	if (n > c->d_out_cap) {
@@ -837,6 +1026,20 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	st = apply_pending(c, s);
 	if (st) return st;
 	c->state_valid = false;
+	// the automaton scan, while its image is the vocabulary as it is; after toggles the plan's own scan
+	// (which patches one slot per toggle) until two full evaluations in a row met no new toggle
+	ensure_dfa(c);
+	bool use_dfa = c->dfa_state == 1 && c->dfa_enabled;
+	if (use_dfa && c->dfa_version != c->toggle_version) {
+		use_dfa = false;
+		if (++c->dfa_stale_evals >= 2) {
+			if (refresh_dfa(c)) use_dfa = true;
+			else {
+				free_dfa(c);
+				c->dfa_state = -1;
+			}
+		}
+	}
 	TrieDev T = trie_dev(c);
 	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
 	ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
@@ -859,7 +1062,20 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		c->ev = view;
 	}
 	auto mark = [&](int k) -> hipError_t { return ev && (!scan_only || k == 1 || k == 2) ? hipEventRecord(ev[k], s) : hipSuccess; };
-	if (c->scan_path == 2) {
+	c->dfa_used_last = use_dfa;
+	if (use_dfa) {
+		// prepare (cursors), scan (clears and presets the output itself), fix-up, two histograms, cold counters
+		const StreamDev Qm{c->d_dstream_m, c->dstream_cap, c->d_dfill_m, c->d_dcursor};
+		const StreamDev Qa{c->d_dstream_a, c->dstream_cap, c->d_dfill_a, c->d_dcursor + 4};
+		const DfaDev A = dfa_dev(c);
+		const DfaWork W = dfa_work(c);
+		launch_dfa_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Qm, Qa, c->dplan.blocks * c->dplan.waves_per_block, c->d_dcursor + 8, s);
+		launch_dfa_scan(A, W, Qm, Qa, c->dplan, s, OutInit{d_out, (uint32_t)c->V, c->D, c->total}, ev ? ev[1] : nullptr, ev ? ev[2] : nullptr);
+		launch_dfa_fixup(A, W, c->d_dcodes, c->d_dcursor + 8, ++c->dfa_epoch, d_out, (uint32_t)c->V + 3, s);
+		launch_histogram_events(Qm, A.lds_slots, c->d_dev_miss, c->d_dpool, d_out, (uint32_t)c->V + 3, c->d_dslab, c->dslab_blocks, s);
+		launch_histogram_events(Qa, A.lds_slots, c->d_dev_arr, c->d_dpool, d_out, (uint32_t)c->V + 3, c->d_dslab, c->dslab_blocks, s);
+		launch_dfa_cold_reduce(A, W, d_out, (uint32_t)c->V + 3, s);
+	} else if (c->scan_path == 2) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 		const uint32_t first_batches = c->d_tprep ? c->rplan.blocks * c->rplan.waves_per_block : 0u;
 		const bool ready = first_batches != 0 && c->stream_ready == first_batches;
@@ -1209,6 +1425,10 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->knob_incr_div = getenv("TOKSCORE_INCR_DIV") ? std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)) : 0;
 	c->knob_toggle_items = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 32ull << 20));
 	c->tg_list_hint = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_LIST", 8192));
+	c->dfa_enabled = env_u64("TOKSCORE_DFA", 1) != 0;
+	c->dfa_max_slots = std::max<uint64_t>(1024, env_u64("TOKSCORE_DFA_SLOTS", 6u << 20));
+	c->dfa_chains = (uint32_t)env_u64("TOKSCORE_DFA_CHAINS", 0);
+	c->dfa_lds_cap = (uint32_t)env_u64("TOKSCORE_DFA_LDS", 0);
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
@@ -1314,6 +1534,10 @@ int tokscore_toggle(tokscore_ctx *c, uint64_t token_index, int enable) {
 	// The device copy is patched by the next evaluation (apply_pending): an incremental
 	// re-score first takes back what the OLD trie counted in the chunks the token occurs in.
 	if (slot >= 0 && !c->hostonly && c->device_trie_valid) c->pending.emplace_back(token_index, slot);
+	if (slot >= 0 || sslot >= 0) {
+		c->toggle_version++;
+		c->dfa_stale_evals = 0;
+	}
 	return TOKSCORE_OK;
 }
 
@@ -2004,6 +2228,19 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 	}
 	info->rescored_chunks = c->rescored_chunks;
 	info->toggle_streams = c->toggle_items;
+	info->base_scan_path = info->scan_path;
+	if (c->plan_valid && c->dfa_state == 1) {
+		info->dfa_slots = c->dimg.nslots;
+		info->dfa_lds_slots = std::min<uint32_t>(c->dplan.lds_slots, c->dimg.nslots);
+		info->dfa_virtual_slots = c->dimg.virtual_slots;
+		info->dfa_active = c->dfa_used_last ? 1u : 0u;
+		info->dfa_chains = c->dplan.chains;
+		info->dfa_range_bytes = c->dplan.range_bytes;
+		info->dfa_hot_fraction = c->dimg.hot_fraction(info->dfa_lds_slots);
+		info->dfa_build_ms = c->dfa_build_ms;
+		info->dfa_plan_ms = c->dfa_plan_ms;
+		if (c->dfa_used_last) info->scan_path = 2;
+	}
 	return TOKSCORE_OK;
 }
 
@@ -2062,6 +2299,25 @@ int tokscore_hosttrie_longest(tokscore_ctx *c, const uint8_t *text, uint64_t n, 
 		c->device_trie_valid = false;
 	}
 	VocabTrie::Longest(c->packed, text, n, len, id);
+	return TOKSCORE_OK;
+}
+
+int tokscore_hostdfa_check(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t max_slots,
+                           uint64_t *counts, uint64_t *total_tokens, uint64_t stats[8]) {
+	if (!c || !off || !counts || !total_tokens || (!bytes && D && off[D] != off[0])) return TOKSCORE_E_ARG;
+	if (!c->vocab_set) return fail(c, TOKSCORE_E_STATE, "vocabulary not set");
+	DfaImage img;
+	DfaOptions opt;
+	if (max_slots) opt.max_slots = max_slots;
+	opt.sample = bytes ? bytes + off[0] : nullptr;
+	opt.sample_bytes = std::min<uint64_t>(off[D] - off[0], kSampleBytes);
+	std::string why;
+	if (!c->trie.BuildDfa(&img, opt, &why)) return fail(c, TOKSCORE_E_VOCAB, why);
+	DfaRun(img, bytes, off, D, c->V, counts, total_tokens);
+	if (stats) {
+		stats[0] = img.nslots, stats[1] = img.real_slots, stats[2] = img.virtual_slots, stats[3] = img.ncodes;
+		stats[4] = img.stride, stats[5] = img.max_events, stats[6] = img.sample_steps, stats[7] = img.sample_virtual;
+	}
 	return TOKSCORE_OK;
 }
 

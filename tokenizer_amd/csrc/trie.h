@@ -14,6 +14,9 @@
 
 namespace tokscore {
 
+struct DfaImage;   // dfa.h
+struct DfaOptions;
+
 // Packed slot t (one byte-trie node), two 32-bit words:
 //   w0 = label : 8   the byte on the edge from the parent
 //        valid : 1   0 for empty slots and for the root
@@ -105,6 +108,11 @@ public:
 	// that is not valid UTF-8 on its own stays 0).
 	void AccumulateEnds(const uint64_t *slot_ends, uint32_t max_cp, uint64_t *counts) const;
 	bool Enabled(uint64_t token) const { return token < V_ && enabled_[token] != 0; }
+
+	// The vocabulary as it is now (enabled entries only) as the one-transition-per-byte automaton of
+	// dfa.h.  False (with *why set) when it cannot be built: too many distinct edge bytes, or more
+	// slots than opt.max_slots.
+	bool BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why) const;
 
 	// Rows of a per-string table (one row per distinct non-empty token string): slot_row[t] = row
 	// of the node at slot t or -1, tok_row[i] = row of token i's string or -1.  After Pack.
