@@ -216,12 +216,12 @@ typedef struct {
 	 * evaluations whenever its image can be built for the vocabulary; 0 everywhere when it cannot */
 	uint64_t dfa_slots;         /* 4-byte slots of the image, real + virtual + empty */
 	uint64_t dfa_virtual_slots;
-	uint32_t dfa_lds_slots;     /* its hot-first prefix staged in LDS; the rest is read from L2 */
+	uint32_t dfa_lds_slots;     /* slots of the array staged in LDS (the entries the corpus sample used); the rest is read from L2 */
 	uint32_t dfa_active;        /* 1: the last full evaluation ran on it */
 	uint32_t dfa_chains;        /* ranges of the corpus each lane steps side by side */
 	uint32_t dfa_range_bytes;
 	uint32_t base_scan_path;    /* the plan's own scan (incremental re-scores, moves, evaluations after toggles) */
-	uint32_t reserved0;
+	uint32_t dfa_lds_used;      /* entries in the LDS array */
 	double dfa_hot_fraction;    /* share of the hotness sample's lookups that fall on the LDS prefix */
 	double dfa_build_ms;        /* host time of the last image build */
 	double dfa_plan_ms;         /* image + prepared corpus + buffers, once per corpus and vocabulary */
@@ -265,12 +265,12 @@ int tokscore_hosttrie_longest(tokscore_ctx *ctx, const uint8_t *text, uint64_t n
  * (toggles included) with the documents as the hotness sample, runs it over the documents on the
  * host exactly as the scan kernel steps it, and returns what its events add up to -- counts[V+3]
  * and total_tokens as tokscore_score defines them (SolutionFile.cpp:83-100, main.cpp:38-43).
- * max_slots = 0: the library's default limit.  stats (may be NULL): slots, real slots, virtual
- * slots, codes, stride of the depth-1 rows, longest event list, sample steps, of those on virtual
- * slots.  TOKSCORE_E_VOCAB when the image cannot be built (the scoring entry points then use the
+ * max_slots = 0: the library's default limit; lds_slots = 0: the LDS array's default size.  stats
+ * (may be NULL): slots, real entries, virtual entries, codes, entries in the LDS array, reads
+ * of the global array during the run, sample steps, of those on virtual entries.  TOKSCORE_E_VOCAB when the image cannot be built (the scoring entry points then use the
  * other scan paths).  Never used by any scoring entry point. */
 int tokscore_hostdfa_check(tokscore_ctx *ctx, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t max_slots,
-                           uint64_t *counts, uint64_t *total_tokens, uint64_t stats[8]);
+                           uint32_t lds_slots, uint64_t *counts, uint64_t *total_tokens, uint64_t stats[8]);
 
 /* Contexts without a GPU, for the host-side checks above only: set_vocab and
  * hosttrie_longest work, every scoring call fails with TOKSCORE_E_NO_DEVICE. */

@@ -32,7 +32,7 @@ class TokscoreInfo(C.Structure):
                 ("id_bits", C.c_uint32), ("scan_path", C.c_uint32), ("rescored_chunks", C.c_uint32),
                 ("toggle_streams", C.c_uint64), ("dfa_slots", C.c_uint64), ("dfa_virtual_slots", C.c_uint64),
                 ("dfa_lds_slots", C.c_uint32), ("dfa_active", C.c_uint32), ("dfa_chains", C.c_uint32),
-                ("dfa_range_bytes", C.c_uint32), ("base_scan_path", C.c_uint32), ("reserved0", C.c_uint32),
+                ("dfa_range_bytes", C.c_uint32), ("base_scan_path", C.c_uint32), ("dfa_lds_used", C.c_uint32),
                 ("dfa_hot_fraction", C.c_double), ("dfa_build_ms", C.c_double), ("dfa_plan_ms", C.c_double)]
 
 
@@ -66,7 +66,7 @@ _SIGNATURES = [
     ("tokscore_drain_timings", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     ("tokscore_set_timing", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     ("tokscore_hosttrie_longest", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u64p]),
-    ("tokscore_hostdfa_check", C.c_int, [C.c_void_p, _u8p, _u64p, C.c_uint64, C.c_uint64, _u64p, _u64p, _u64p]),
+    ("tokscore_hostdfa_check", C.c_int, [C.c_void_p, _u8p, _u64p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p, _u64p, _u64p]),
     ("tokscore_probe_read_bandwidth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
 ]
 EXPORTED_SYMBOLS = [s[0] for s in _SIGNATURES]
@@ -278,7 +278,7 @@ class Scorer:
         self._check(self._lib.tokscore_hosttrie_longest(self._h, _p8(a), len(text), C.byref(ln), C.byref(tid)))
         return int(ln.value), int(tid.value)
 
-    def hostdfa_check(self, corpus: np.ndarray, doc_off: np.ndarray, max_slots: int = 0):
+    def hostdfa_check(self, corpus: np.ndarray, doc_off: np.ndarray, max_slots: int = 0, lds_slots: int = 0):
         """Host self-check of the scan automaton (tokscore_hostdfa_check): -> (counts[V+3],
         total_tokens, stats[8]) from running the image over the documents on the CPU."""
         b = np.ascontiguousarray(corpus, dtype=np.uint8)
@@ -288,6 +288,6 @@ class Scorer:
         counts = np.zeros(self.V + 3, dtype=np.uint64)
         tt = C.c_uint64()
         stats = np.zeros(8, dtype=np.uint64)
-        self._check(self._lib.tokscore_hostdfa_check(self._h, _p8(b), _p64(o), len(o) - 1, max_slots, _p64(counts),
+        self._check(self._lib.tokscore_hostdfa_check(self._h, _p8(b), _p64(o), len(o) - 1, max_slots, lds_slots, _p64(counts),
                                                      C.byref(tt), _p64(stats)))
         return counts, int(tt.value), stats

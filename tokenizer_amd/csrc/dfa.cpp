@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -21,12 +23,9 @@ struct Entry {
 };
 } // namespace
 
-double DfaImage::hot_fraction(uint32_t n) const {
-	if (sample_steps == 0 || sample_slot_hits.empty()) return 1.0;
-	uint64_t s = 0;
-	const size_t m = std::min<size_t>(n, sample_slot_hits.size());
-	for (size_t i = 0; i < m; i++) s += sample_slot_hits[i];
-	return (double)s / (double)sample_steps;
+double DfaImage::hot_fraction() const {
+	if (sample_steps == 0) return 1.0;
+	return 1.0 - (double)sample_cold / (double)sample_steps;
 }
 
 void DfaImage::event_ids(uint32_t ev, std::vector<uint32_t> *out) const {
@@ -243,43 +242,113 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			}
 		}
 	}
+	// ---- which entries and rows are worth LDS ----
+	// The global array holds the whole automaton: every row complete, beyond hot_cap.  The LDS array
+	// is an overlay for the rows the sample visited, the rows with the most lookups per LDS entry
+	// first, for as long as entries fit: a row is there COMPLETE, or PARTIAL -- only the entries the
+	// sample used; a miss in a partial row proves nothing, so it is looked up again in the row's
+	// complete copy -- whichever is worth the slots: the rows with the most misses per unused entry
+	// are completed while slots are left.
+	const uint32_t hot_cap = std::max<uint32_t>(opt.lds_slots, 2 * ncodes + 64);
+	const bool sampled = out->sample_steps != 0;
+	const bool can_split = ncodes <= 127; // (with more codes the label takes the bit that marks a partial row)
+	std::vector<uint32_t> nhot(S, 0), ncold(S, 0);
+	std::vector<uint64_t> w_miss(S, 0);
+	std::vector<uint8_t> is_d1(S, 0), klass(S, 0); // klass: 0 global array only, 1 complete in LDS, 2 partial in LDS
+	for (uint32_t c = 0; c < ncodes; c++) is_d1[d1[c]] = 1;
+	if (!sampled) { // no sample: breadth-first, everything counts as used
+		for (uint32_t s = 1; s < N; s++) w_row[s] = 1 + (max_len_ + 1 - std::min<uint64_t>(depth_[s], max_len_ + 1));
+		std::fill(w_ent.begin(), w_ent.end(), 1u);
+	}
+	for (uint32_t s = 1; s < S; s++) {
+		uint64_t used_sum = 0;
+		for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) {
+			if (w_ent[j] || is_d1[s]) nhot[s]++;
+			else ncold[s]++;
+			used_sum += w_ent[j];
+		}
+		w_miss[s] = sampled && w_row[s] > used_sum ? w_row[s] - used_sum : 0;
+	}
+	uint64_t d1_slots = ncodes;
+	for (uint32_t c = 1; c < ncodes; c++) d1_slots += row_off[d1[c] + 1] - row_off[d1[c]];
+	std::vector<uint32_t> order; // LDS candidates, best first
+	for (uint32_t s = 1; s < S; s++) {
+		if (is_d1[s] || row_off[s + 1] == row_off[s] || w_row[s] == 0) continue;
+		order.push_back(s);
+	}
+	{
+		auto cost = [&](uint32_t s) { return can_split ? std::max<uint32_t>(1, nhot[s]) : nhot[s] + ncold[s]; };
+		auto value = [&](uint32_t s) { return (double)w_row[s] / (double)cost(s); };
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return value(a) > value(b); });
+		const double room = hot_cap > d1_slots + 2 * ncodes ? (double)(hot_cap - d1_slots - 2 * ncodes) : 0.0;
+		double taken = 0;
+		std::vector<uint32_t> partial;
+		for (uint32_t s : order) {
+			if (taken + cost(s) > 0.95 * room) break; // (slack: first-fit leaves holes)
+			taken += cost(s);
+			klass[s] = can_split && ncold[s] ? 2 : 1;
+			if (klass[s] == 2) partial.push_back(s);
+		}
+		std::stable_sort(partial.begin(), partial.end(), [&](uint32_t a, uint32_t b) {
+			return (double)w_miss[a] / ncold[a] > (double)w_miss[b] / ncold[b];
+		});
+		for (uint32_t s : partial) {
+			if (w_miss[s] == 0) break;
+			if (taken + ncold[s] > 0.995 * room) continue;
+			taken += ncold[s];
+			klass[s] = 1;
+		}
+	}
 	// ---- placement ----
-	std::vector<uint8_t> used(4096, 0), base_used(4096, 0);
-	std::vector<uint32_t> next_free(4096);
-	for (uint32_t i = 0; i < 4096; i++) next_free[i] = i;
-	auto ensure = [&](uint64_t n) {
-		if (used.size() < n) {
-			const uint64_t old = used.size(), m = std::max<uint64_t>(n, old * 2);
-			used.resize(m, 0);
-			base_used.resize(m, 0);
-			next_free.resize(m);
-			for (uint64_t i = old; i < m; i++) next_free[i] = (uint32_t)i;
+	struct Occ {
+		std::vector<uint8_t> used, base_used;
+		std::vector<uint32_t> next_free;
+		void ensure(uint64_t n) {
+			if (used.size() < n) {
+				const uint64_t old = used.size(), m = std::max<uint64_t>(n, std::max<uint64_t>(4096, old * 2));
+				used.resize(m, 0);
+				base_used.resize(m, 0);
+				next_free.resize(m);
+				for (uint64_t i = old; i < m; i++) next_free[i] = (uint32_t)i;
+			}
 		}
-	};
-	auto find_free = [&](uint64_t s) -> uint64_t {
-		ensure(s + 1);
-		uint64_t r = s;
-		while (next_free[r] != r) {
-			r = next_free[r];
-			ensure(r + 1);
+		uint64_t find_free(uint64_t s) {
+			ensure(s + 1);
+			uint64_t r = s;
+			while (next_free[r] != r) {
+				r = next_free[r];
+				ensure(r + 1);
+			}
+			while (next_free[s] != r) {
+				const uint64_t t = next_free[s];
+				next_free[s] = (uint32_t)r;
+				s = t;
+			}
+			return r;
 		}
-		while (next_free[s] != r) {
-			const uint64_t t = next_free[s];
-			next_free[s] = (uint32_t)r;
-			s = t;
+		bool is_used(uint64_t t) {
+			ensure(t + 1);
+			return used[t] != 0;
 		}
-		return r;
+		void take(uint64_t t) {
+			ensure(t + 2);
+			used[t] = 1;
+			next_free[t] = (uint32_t)(t + 1);
+		}
+		bool base_taken(uint64_t b) {
+			ensure(b + 1);
+			return base_used[b] != 0;
+		}
+		void take_base(uint64_t b) {
+			ensure(b + 1);
+			base_used[b] = 1;
+		}
+		uint64_t max_used = 0, max_base = 0, base_cursor = 1;
 	};
-	uint64_t max_used = 0, max_base = 0;
-	auto take = [&](uint64_t slot) {
-		ensure(slot + 2);
-		used[slot] = 1;
-		next_free[slot] = (uint32_t)(slot + 1);
-		max_used = std::max(max_used, slot);
-	};
-	std::vector<uint32_t> base(S, 0);
+	Occ H, G; // the LDS array [0, hot_cap) and the global array [hot_cap, ...): bases are unique within each
+	std::vector<uint32_t> base_h(S, 0), base_g(S, 0);
 	// the root row: dense at base 0, slot c = the depth-1 state of code c
-	for (uint32_t c = 0; c < ncodes; c++) take(c);
+	for (uint32_t c = 0; c < ncodes; c++) H.take(c);
 	// depth-1 rows at c * stride: the smallest stride whose occupied slots are all different and clear of the root row
 	uint32_t stride = 0;
 	{
@@ -297,113 +366,184 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 		}
 		if (!stride) stride = ncodes; // (always fits: rows then do not overlap at all)
 	}
-	ensure((uint64_t)ncodes * stride + ncodes + 2);
+	if ((uint64_t)(ncodes - 1) * stride + ncodes > hot_cap) return fail("the depth-1 rows do not fit the LDS array");
 	for (uint32_t c = 0; c < ncodes; c++) {
-		base[d1[c]] = c * stride;
-		base_used[c * stride] = 1;
-		max_base = std::max<uint64_t>(max_base, c * stride);
+		base_h[d1[c]] = c * stride;
+		klass[d1[c]] = 1;
+		H.take_base(c * stride);
 		if (c == 0) continue;
-		for (uint64_t j = row_off[d1[c]]; j < row_off[d1[c] + 1]; j++) take(c * stride + ent[j].code);
+		for (uint64_t j = row_off[d1[c]]; j < row_off[d1[c] + 1]; j++) H.take(c * stride + ent[j].code);
 	}
 	// the base of states without a row: a value no state has, so no slot "belongs" to it
 	uint32_t empty_base = 1;
-	while (base_used[empty_base]) empty_base++, ensure(empty_base + 1);
-	base_used[empty_base] = 1;
-	max_base = std::max<uint64_t>(max_base, empty_base);
-	// every other row, the busiest first
-	std::vector<uint32_t> order;
-	{
-		std::vector<uint8_t> is_d1(S, 0);
-		for (uint32_t c = 0; c < ncodes; c++) is_d1[d1[c]] = 1;
-		for (uint32_t s = 1; s < S; s++) {
-			if (is_d1[s]) continue;
-			if (row_off[s + 1] == row_off[s]) {
-				base[s] = empty_base;
-				continue;
-			}
-			order.push_back(s);
-		}
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w_row[a] > w_row[b]; });
-	}
+	while (H.base_taken(empty_base)) empty_base++;
+	H.take_base(empty_base);
+	// A row into occupancy `occ` with bases in [lo, hi) (hi = 0: no upper limit); only_used: just the
+	// entries the sample used.  False when nothing fits below hi.
 	const uint64_t slot_limit = std::min<uint64_t>(opt.max_slots, DfaImage::kMaxSlots);
-	for (uint32_t s : order) {
+	auto place = [&](Occ &occ, uint32_t s, bool only_used, uint64_t lo, uint64_t hi, uint32_t *base_out) -> bool {
 		const Entry *e = ent.data() + row_off[s];
 		const uint32_t nc = (uint32_t)(row_off[s + 1] - row_off[s]);
-		const uint32_t c0 = e[0].code;
-		uint64_t t = find_free(std::max<uint64_t>(1, (uint64_t)c0 + 1));
+		auto in = [&](uint32_t i) { return !only_used || w_ent[row_off[s] + i] != 0; };
+		uint32_t lead = 0;
+		while (lead < nc && !in(lead)) lead++;
+		if (lead == nc) { // nothing to store (a partial row none of whose entries was used): any base of its own
+			uint64_t b = std::max<uint64_t>(lo, occ.base_cursor);
+			while (occ.base_taken(b)) b++;
+			if (hi && b >= hi) return false;
+			occ.base_cursor = b + 1;
+			occ.take_base(b);
+			occ.max_base = std::max(occ.max_base, b);
+			*base_out = (uint32_t)b;
+			return true;
+		}
+		const uint32_t c0 = e[lead].code;
+		uint64_t t = occ.find_free(std::max<uint64_t>(lo + c0, (uint64_t)c0 + 1));
 		uint64_t b = 0;
 		for (uint32_t tries = 0;; tries++) {
 			b = t - c0;
-			ensure(b + ncodes + 1);
-			bool ok = !base_used[b];
-			for (uint32_t i = 0; ok && i < nc; i++) ok = !used[b + e[i].code];
+			if (hi && b >= hi) return false;
+			bool ok = !occ.base_taken(b);
+			for (uint32_t i = lead; ok && i < nc; i++) ok = !in(i) || !occ.is_used(b + e[i].code);
 			if (ok) break;
-			if (tries >= 512) { // (deep vocabularies: see VocabTrie::Pack)
-				for (b = max_base + 1;; b++) {
-					ensure(b + ncodes + 1);
-					bool fits = true;
-					for (uint32_t i = 0; fits && i < nc; i++) fits = !used[b + e[i].code];
+			if (tries >= 512 && !hi) { // (deep vocabularies: see VocabTrie::Pack) beyond everything placed so far
+				for (b = std::max<uint64_t>(occ.max_base + 1, lo);; b++) {
+					bool fits = !occ.base_taken(b);
+					for (uint32_t i = lead; fits && i < nc; i++) fits = !in(i) || !occ.is_used(b + e[i].code);
 					if (fits) break;
 				}
 				break;
 			}
-			t = find_free(t + 1);
+			t = occ.find_free(t + 1);
 		}
-		base_used[b] = 1;
-		max_base = std::max(max_base, b);
-		base[s] = (uint32_t)b;
-		for (uint32_t i = 0; i < nc; i++) take(b + e[i].code);
-		if (max_used + ncodes + 1 > slot_limit) return fail("the automaton needs more slots than the limit");
+		occ.take_base(b);
+		occ.max_base = std::max(occ.max_base, b);
+		*base_out = (uint32_t)b;
+		for (uint32_t i = lead; i < nc; i++)
+			if (in(i)) {
+				occ.take(b + e[i].code);
+				occ.max_used = std::max<uint64_t>(occ.max_used, b + e[i].code);
+			}
+		return true;
+	};
+	const uint64_t hot_hi = hot_cap - ncodes; // an LDS row's base: every slot it can probe is below hot_cap
+	uint32_t n_sel = 0, n_demoted = 0;
+	for (uint32_t s : order) {
+		if (klass[s] == 0) continue;
+		n_sel++;
+		if (klass[s] == 1 && !place(H, s, false, 1, hot_hi, &base_h[s])) klass[s] = can_split && ncold[s] ? 2 : 0;
+		if (klass[s] == 2 && !place(H, s, true, 1, hot_hi, &base_h[s])) klass[s] = 0;
+		n_demoted += klass[s] == 0;
 	}
-	const uint64_t nslots = std::max(max_used + 1, max_base + ncodes + 1); // base + any code is a readable slot
+	// the whole automaton in the global array (the depth-1 rows excepted: they are complete in LDS)
+	G.max_base = hot_cap - 1;
+	for (uint32_t s = 1; s < S; s++) {
+		if (is_d1[s] || row_off[s + 1] == row_off[s]) continue;
+		place(G, s, false, hot_cap, 0, &base_g[s]);
+		if (G.max_used + ncodes + 1 > slot_limit) return fail("the automaton needs more slots than the limit");
+	}
+	const uint64_t nslots = std::max<uint64_t>(std::max(G.max_used + 1, G.max_base + ncodes + 1), hot_cap); // base + any code is a readable slot
 	if (nslots > slot_limit) return fail("the automaton needs more slots than the limit");
 	// ---- the image ----
 	out->ncodes = ncodes;
 	out->stride = stride;
 	out->nslots = (uint32_t)nslots;
+	out->hot_slots = hot_cap;
+	out->label_bits = can_split ? 7u : 8u;
+	out->inc_bit = can_split ? 1u << 31 : 0u;
+	out->hot.assign(hot_cap, DfaImage::kEmptyWord);
 	out->slot.assign(nslots, DfaImage::kEmptyWord);
+	out->crow.assign(hot_cap, 0);
 	out->ev_miss.assign(nslots, DfaImage::kEvNone);
 	out->ev_arr.assign(nslots, DfaImage::kEvNone);
-	out->sample_slot_hits.assign(nslots, 0);
-	out->real_slots = out->virtual_slots = 0;
+	out->real_slots = out->virtual_slots = out->hot_used = 0;
+	// the word of a state: where its next byte is looked up -- its LDS row if it has one
+	auto state_word = [&](uint32_t s) -> uint32_t {
+		if (is_d1[s]) return base_h[s];
+		if (row_off[s + 1] == row_off[s]) return empty_base;
+		if (klass[s] == 1) return base_h[s];
+		if (klass[s] == 2) return base_h[s] | out->inc_bit;
+		return base_g[s];
+	};
 	for (uint32_t c = 0; c < ncodes; c++) {
-		out->slot[c] = c << DfaImage::kLabelShift | base[d1[c]];
+		out->hot[c] = c << DfaImage::kLabelShift | state_word(d1[c]);
 		out->ev_miss[c] = M[d1[c]];
-		out->sample_slot_hits[c] = w_d1[c];
 		out->real_slots++;
+		out->hot_used++;
 	}
+	uint64_t cold_steps = 0; // sample lookups that need the global array
+	uint32_t n_partial = 0;
 	for (uint32_t s = 1; s < S; s++) {
+		if (row_off[s + 1] == row_off[s]) continue;
+		if (!is_d1[s]) {
+			if (klass[s] == 0) cold_steps += sampled ? w_row[s] : 0;
+			else if (klass[s] == 2) cold_steps += w_miss[s], n_partial++, out->crow[base_h[s]] = base_g[s];
+		}
 		for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) {
 			const Entry &e = ent[j];
-			const uint32_t t = base[s] + e.code;
-			out->slot[t] = (uint32_t)e.code << DfaImage::kLabelShift | (e.virt ? DfaImage::kArr : 0u) | base[e.target];
-			out->ev_miss[t] = M[e.target];
-			out->ev_arr[t] = e.arr;
-			out->sample_slot_hits[t] = w_ent[j];
+			const uint32_t word = (uint32_t)e.code << DfaImage::kLabelShift | (e.virt ? DfaImage::kArr : 0u) | state_word(e.target);
+			if (klass[s] == 1 || (klass[s] == 2 && w_ent[j] != 0)) {
+				const uint32_t t = base_h[s] + e.code;
+				out->hot[t] = word;
+				out->ev_miss[t] = M[e.target];
+				out->ev_arr[t] = e.arr;
+				out->hot_used++;
+			}
+			if (!is_d1[s]) {
+				const uint32_t t = base_g[s] + e.code;
+				out->slot[t] = word;
+				out->ev_miss[t] = M[e.target];
+				out->ev_arr[t] = e.arr;
+			}
 			if (e.virt) out->virtual_slots++;
 			else out->real_slots++;
 		}
 	}
+	out->sample_cold = sampled ? cold_steps : 0;
 	out->max_events = max_events;
 	out->valid = true;
+	if (getenv("TOKSCORE_TRACE_HOST"))
+		fprintf(stderr, "BuildDfa: %u slots (%u real, %u virtual entries), LDS array %u of %u used (%zu rows visited, %u chosen, %u found no place, %u partial), "
+		        "%u codes, stride %u; sample: %.4f virtual, %.4f miss, %.6f of the lookups beyond LDS\n",
+		        out->nslots, out->real_slots, out->virtual_slots, out->hot_used, out->hot_slots, order.size(), n_sel, n_demoted, n_partial, ncodes, stride,
+		        (double)out->sample_virtual / std::max<uint64_t>(1, out->sample_steps),
+		        (double)out->sample_miss / std::max<uint64_t>(1, out->sample_steps), (double)out->sample_cold / std::max<uint64_t>(1, out->sample_steps));
 	return true;
 }
 
 void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t V, uint64_t *counts,
-            uint64_t *total_tokens) {
+            uint64_t *total_tokens, uint64_t *global_reads) {
+	uint64_t n_global = 0;
 	for (uint64_t i = 0; i < V + 3; i++) counts[i] = 0;
 	*total_tokens = 0;
-	std::vector<uint64_t> n_miss(img.nslots, 0), n_arr(img.nslots, 0);
+	std::vector<uint64_t> n_miss(img.ev_miss.size(), 0), n_arr(img.ev_arr.size(), 0);
 	uint32_t S = img.start_word(), U = 0;
+	const uint32_t lmask = (1u << img.label_bits) - 1;
+	auto label = [&](uint32_t x) { return (x >> DfaImage::kLabelShift) & lmask; };
 	for (uint64_t d = 0; d < D; d++) {
 		for (uint64_t p = off[d]; p <= off[d + 1]; p++) {
 			const uint32_t c = p < off[d + 1] ? img.code[ascii_lower(bytes[p])] : 0u;
-			const uint32_t t = (S & DfaImage::kBaseMask) + c;
-			const uint32_t x = img.slot[t];
-			if ((x >> DfaImage::kLabelShift) == c) {
-				if (x & DfaImage::kArr) n_arr[t]++;
+			const uint32_t b = S & DfaImage::kBaseMask, t = b + c;
+			uint32_t x, id = t;
+			bool hit;
+			if (t < img.hot_slots) {
+				x = img.hot[t];
+				hit = label(x) == c;
+				if (!hit && (S & img.inc_bit)) { // a partial row: the row's complete copy decides
+					n_global += 2;
+					id = img.crow[b] + c;
+					x = img.slot[id];
+					hit = label(x) == c;
+				}
+			} else {
+				n_global++;
+				x = img.slot[t];
+				hit = label(x) == c;
+			}
+			if (hit) {
+				if (x & DfaImage::kArr) n_arr[id]++;
 				S = x;
-				U = t;
+				U = id;
 			} else {
 				n_miss[U]++;
 				S = c * img.stride;
@@ -413,7 +553,7 @@ void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint
 	}
 	// (the run ends in the separator's state: nothing is pending)
 	std::vector<uint32_t> ids;
-	for (uint32_t t = 0; t < img.nslots; t++) {
+	for (size_t t = 0; t < n_miss.size(); t++) {
 		for (int kind = 0; kind < 2; kind++) {
 			const uint64_t n = kind ? n_arr[t] : n_miss[t];
 			if (!n) continue;
@@ -426,6 +566,7 @@ void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint
 		}
 	}
 	counts[0] = counts[1] = D; // START / END once per document (SolutionFile.cpp:85,98)
+	if (global_reads) *global_reads = n_global;
 }
 
 } // namespace tokscore

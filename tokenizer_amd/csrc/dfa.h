@@ -23,8 +23,8 @@
 // Token counts come from events, not from ids: the kernel logs the slot whose state it left by a miss
 // (ev_miss[slot] = every token of the chain) and the virtual slot it arrived on (ev_arr[slot]); the
 // histogram over slots is turned into counts[id] with these tables at the end of an evaluation.
-// Slots are ordered hot-first (a 2 MB sample of the corpus run through the automaton): the first
-// `lds_slots` live in LDS, the rest is read from L2.
+// What LDS holds is chosen entry by entry (a 2 MB sample of the corpus run through the automaton says
+// which entries are used): see DfaImage below.
 #pragma once
 
 #include <cstdint>
@@ -34,8 +34,10 @@
 namespace tokscore {
 
 struct DfaImage {
-	// slot word: label (code) : 8 | kArr : 1 | base : 23.  The state a slot stands for looks its next
-	// byte up at slot base + code.  Empty slots carry label 0xFF, which no code equals.
+	// slot word: partial : 1 | label (code) : 7 | kArr : 1 | base : 23 -- or, with more than 127 codes,
+	// label : 8 | kArr : 1 | base : 23 and no partial rows (label_bits, inc_bit).  The state a slot
+	// stands for looks its next byte up at slot base + code; `partial` says that state's LDS row is a
+	// partial one.  Empty slots carry the all-ones label, which no code equals.
 	static constexpr uint32_t kLabelShift = 24;
 	static constexpr uint32_t kArr = 0x800000u;
 	static constexpr uint32_t kBaseMask = 0x7FFFFFu;
@@ -46,9 +48,24 @@ struct DfaImage {
 	static constexpr uint32_t kEvNone = 0xFFFFFFFFu;
 	static constexpr uint32_t kEvList = 0x80000000u;
 
+	// Two arrays over one index space.  `slot` [hot_slots, nslots) holds the whole automaton, read from
+	// global memory (L2): every state's row, complete.  `hot` [0, hot_slots) is what the scan keeps in
+	// LDS: the root row, the depth-1 rows, and an overlay for the rows the sample visited -- a row is
+	// there COMPLETE, or PARTIAL: only the entries the sample used; a miss in a partial row (inc_bit
+	// set in its state's word) is looked up again at crow[base] + code, the row's complete copy.  A
+	// state's word names its LDS row when it has one, so a walk that left LDS is back at the next
+	// entry that leads to a visited state.  An entry's event index is the index of the slot it was
+	// read from (either array).
+	std::vector<uint32_t> hot;
 	std::vector<uint32_t> slot;
-	std::vector<uint32_t> ev_miss; // per slot: what leaving its state by a miss emits
-	std::vector<uint32_t> ev_arr;  // per slot: what arriving on it emits (kArr slots only)
+	std::vector<uint32_t> crow;    // [hot_slots] by LDS base: base of the same state's row in `slot` (partial rows)
+	std::vector<uint32_t> ev_miss; // [nslots] by event index: what leaving the entry's state by a miss emits
+	std::vector<uint32_t> ev_arr;  // ... what arriving on it emits (kArr entries only)
+	uint32_t hot_slots = 0;        // = DfaOptions::lds_slots
+	uint32_t label_bits = 8;       // 7 when the partial bit exists
+	uint32_t inc_bit = 0;          // 1 << 31 then (the word's sign: one compare in the kernel)
+	uint32_t hot_used = 0;         // entries in `hot`
+	uint64_t sample_cold = 0;      // sample lookups that needed `slot`
 	std::vector<uint32_t> pool;
 	uint8_t code[256] = {};
 	uint32_t ncodes = 0;  // code 0 = document separator, ncodes - 1 = every byte that labels no edge
@@ -61,15 +78,15 @@ struct DfaImage {
 	bool valid = false;
 
 	// the state after a document separator: slot 0 (the root row is the separator's row)
-	uint32_t start_word() const { return slot.empty() ? 0u : slot[0]; }
-	// fraction of the sample's lookups that fall on slots [0, n)
-	std::vector<uint32_t> sample_slot_hits; // per slot, for hot_fraction
-	double hot_fraction(uint32_t n) const;
+	uint32_t start_word() const { return hot.empty() ? 0u : hot[0]; }
+	// share of the sample's lookups that `hot` alone answered
+	double hot_fraction() const;
 	// appends an event's ids to out (with repetitions)
 	void event_ids(uint32_t ev, std::vector<uint32_t> *out) const;
 };
 
 struct DfaOptions {
+	uint32_t lds_slots = 40000;    // slots of the LDS array
 	uint64_t max_slots = 6u << 20; // give up above this many slots (virtual slots of deep vocabularies run into tens of millions)
 	const uint8_t *sample = nullptr; // raw corpus bytes for the hot-first order (lower-cased here)
 	uint64_t sample_bytes = 0;
@@ -78,7 +95,8 @@ struct DfaOptions {
 // Host-side check of an image (CPU tests of the builder; never used by a scoring entry point): runs
 // the automaton over documents exactly as the kernel does -- codes of the lower-cased bytes, a
 // separator after every document -- and adds up counts[V + 3] and total_tokens from the events.
+// *global_reads (optional): reads of the global array the run made (a partial row's second look counts two).
 void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t V, uint64_t *counts,
-            uint64_t *total_tokens);
+            uint64_t *total_tokens, uint64_t *global_reads = nullptr);
 
 } // namespace tokscore

@@ -225,12 +225,16 @@ void launch_histogram_events(const StreamDev &Q, uint32_t nslots, const uint32_t
 
 // kernels_dfa.hip -- full evaluation on the one-transition-per-byte automaton (dfa.h)
 struct DfaDev {
-	const uint32_t *slot;    // [nslots, padded to 16 bytes] label : 8 | kArr : 1 | base : 23
-	const uint32_t *ev_miss; // [nslots] event of leaving the slot's state by a miss
-	const uint32_t *ev_arr;  // [nslots] event of arriving on a virtual slot
+	const uint32_t *hot;     // [hot_slots, padded to 16 bytes] the LDS array: label : 8 | kArr : 1 | base : 23
+	const uint32_t *slot;    // [nslots] the global array: the whole automaton, rows at bases >= hot_slots
+	const uint32_t *crow;    // [hot_slots] by LDS base: base of a partial row's complete copy in `slot`
+	const uint32_t *ev_miss; // [nslots] by event index (= slot index in either array): leaving the entry's state by a miss
+	const uint32_t *ev_arr;  // ... arriving on a virtual entry
 	const uint32_t *pool;    // event lists
 	uint32_t nslots;
-	uint32_t lds_slots;      // slots [0, lds_slots) are staged in LDS; events on them go to the streams
+	uint32_t hot_slots;      // events with an index below it go to the streams, the others to counters
+	uint32_t label_bits;     // 7: partial : 1 | label : 7 | kArr | base : 23; 8: label : 8 | kArr | base : 23
+	uint32_t inc_bit;        // the partial bit (0: none): a miss in `hot` from such a state is looked up at crow[base] + code
 	uint32_t stride;         // the depth-1 state of code c has its row at c * stride
 };
 struct DfaWork {
@@ -242,7 +246,7 @@ struct DfaWork {
 	uint2 *exit_a;           // [nranges] state the scan ended the range in
 	uint2 *exit_b;           // [nranges] ... after the fix-up, where exit_tag[g] == the evaluation's epoch
 	uint32_t *exit_tag;
-	uint32_t *cold_miss;     // [nslots - lds_slots] events on slots beyond the LDS prefix (zero between evaluations)
+	uint32_t *cold_miss;     // [nslots] events with index hot_slots + i (zero between evaluations)
 	uint32_t *cold_arr;
 };
 struct DfaScanPlan {
@@ -250,8 +254,9 @@ struct DfaScanPlan {
 	uint32_t lds_slots, lds_bytes;
 	uint32_t range_bytes, nwb;
 };
-// lds_cap: 0, or fewer LDS slots than fit (tests: exercises the lookups and events beyond the prefix)
-bool plan_dfa_scan(uint32_t nslots, uint64_t prep_total, uint32_t num_cus, uint32_t chains_hint, uint32_t lds_cap, DfaScanPlan *plan);
+// dfa_lds_slots_max(lds_cap): slots of the LDS array; lds_cap = 0, or fewer than fit (tests: most lookups
+// and events then go the way of the global array)
+bool plan_dfa_scan(uint32_t hot_slots, uint64_t prep_total, uint32_t num_cus, uint32_t chains_hint, DfaScanPlan *plan);
 uint32_t dfa_lds_slots_max(uint32_t lds_cap);
 uint64_t dfa_stream_capacity_batches(const DfaScanPlan &plan);
 void launch_dfa_transpose(const uint8_t *prep, uint64_t prep_total, uint32_t range_bytes, uint32_t chains, uint64_t nwb,

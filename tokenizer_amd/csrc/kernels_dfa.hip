@@ -30,13 +30,14 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace tokscore {
 
 namespace {
 
 constexpr uint32_t kDfaBatchEntries = kStreamBatch * 512; // u16 entries of one stream batch (32 KiB)
-constexpr uint32_t kLabelShift = 24, kArr = 0x800000u, kBaseMask = 0x7FFFFFu;
+constexpr uint32_t kArr = 0x800000u, kBaseMask = 0x7FFFFFu;
 constexpr uint32_t kEvNone = 0xFFFFFFFFu, kEvList = 0x80000000u;
 
 // The ranges transposed: 8-byte piece p of chain j of lane l of wave block wb at
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(256) dfa_transpose_kernel(const uint8_t *prep,
 // entry states of a new plan: the separator's state everywhere; cursors and fix-up words
 __global__ void __launch_bounds__(256) dfa_reset_states_kernel(uint2 *entry, uint32_t nranges, uint32_t start_word) {
 	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nranges; g += gridDim.x * blockDim.x)
-		entry[g] = uint2{start_word & 0xFFFFFFu, 0u};
+		entry[g] = uint2{start_word & kBaseMask, 0u};
 }
 
 __global__ void __launch_bounds__(256) dfa_prepare_kernel(unsigned long long *out, uint32_t V, unsigned long long D,
@@ -126,9 +127,9 @@ __global__ void __launch_bounds__(1024) dfa_scan_kernel(DfaDev A, DfaWork W, Str
 		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < I.V + 5; i += gridDim.x * blockDim.x)
 			I.out[i] = i < 2 ? I.D : (i == I.V + 4 ? I.total_bytes : 0ull);
 	{
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(A.slot);
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(A.hot);
 		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)img;
-		for (uint32_t i = threadIdx.x; i < (A.lds_slots + 3) / 4; i += blockDim.x) dst[i] = src[i]; // (the image is padded to 16 bytes)
+		for (uint32_t i = threadIdx.x; i < (A.hot_slots + 3) / 4; i += blockDim.x) dst[i] = src[i]; // (the array is padded to 16 bytes)
 	}
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(1024) dfa_scan_kernel(DfaDev A, DfaWork W, Str
 	lm.open_own(Qm, wave_id);
 	la.open_own(Qa, wave_id);
 	const uint32_t pieces = W.range_bytes / 8;
-	const uint32_t lds_slots = A.lds_slots, stride = A.stride;
+	const uint32_t hot_slots = A.hot_slots, inc_bit = A.inc_bit, lmask = (1u << A.label_bits) - 1, stride = A.stride;
 	constexpr uint32_t kHigh = kDfaBatchEntries - 8 * C * 64;
 
 	for (uint32_t wb = wave_id; wb < W.nwb; wb += total_waves) {
@@ -165,22 +166,30 @@ __global__ void __launch_bounds__(1024) dfa_scan_kernel(DfaDev A, DfaWork W, Str
 				for (int j = 0; j < C; j++) {
 					const uint32_t w = k < 4 ? cur[j].x : cur[j].y;
 					const uint32_t c = (w >> (8 * (k & 3))) & 0xFFu;
-					const uint32_t t = (S[j] & 0xFFFFFFu) + c; // (a virtual slot's state carries kArr: beyond LDS, masked below)
-					uint32_t x;
-					if (t < lds_slots) x = img[t];
-					else x = A.slot[t & kBaseMask];
-					const bool hit = (x >> kLabelShift) == c;
+					const uint32_t b = S[j] & kBaseMask, t = b + c;
+					uint32_t x, id = t;
+					if (t < hot_slots) x = img[t];
+					else x = A.slot[t];
+					bool hit = ((x >> 24) & lmask) == c;
+					// a partial row (dfa.h): a miss proves nothing, the row's complete copy in the global array decides
+					const bool again = !hit && (S[j] & inc_bit) != 0;
+					if (__builtin_amdgcn_ballot_w64(again) != 0) {
+						if (again) {
+							id = A.crow[b] + c;
+							x = A.slot[id];
+							hit = ((x >> 24) & lmask) == c;
+						}
+					}
 					const bool arr = hit && (x & kArr) != 0;
-					const uint32_t ts = t & kBaseMask;
-					// the state left by a miss: its slot to the miss stream (or, beyond the LDS prefix, its counter)
-					lm.put(!hit && U[j] < lds_slots, U[j]);
-					if (!hit && U[j] >= lds_slots) atomicAdd(&W.cold_miss[U[j] - lds_slots], 1u);
+					// the state left by a miss: its entry's index to the miss stream (or, beyond the LDS array, its counter)
+					lm.put(!hit && U[j] < hot_slots, U[j]);
+					if (!hit && U[j] >= hot_slots) atomicAdd(&W.cold_miss[U[j] - hot_slots], 1u);
 					if (__builtin_amdgcn_ballot_w64(arr) != 0) {
-						la.put(arr && ts < lds_slots, ts);
-						if (arr && ts >= lds_slots) atomicAdd(&W.cold_arr[ts - lds_slots], 1u);
+						la.put(arr && id < hot_slots, id);
+						if (arr && id >= hot_slots) atomicAdd(&W.cold_arr[id - hot_slots], 1u);
 					}
 					S[j] = hit ? x : c * stride;
-					U[j] = hit ? ts : c;
+					U[j] = hit ? id : c;
 				}
 			}
 #pragma unroll
@@ -189,7 +198,302 @@ __global__ void __launch_bounds__(1024) dfa_scan_kernel(DfaDev A, DfaWork W, Str
 			if (la.cur > kHigh) la.roll(Qa, lane);
 		}
 #pragma unroll
-		for (int j = 0; j < C; j++) W.exit_a[(wb * C + j) * 64 + lane] = uint2{S[j] & 0xFFFFFFu, U[j]};
+		for (int j = 0; j < C; j++) W.exit_a[(wb * C + j) * 64 + lane] = uint2{S[j] & (kBaseMask | inc_bit), U[j]};
+	}
+	lm.close(Qm, lane);
+	la.close(Qa, lane);
+}
+
+// ---- the scan's loop, hand-written for gfx950 -------------------------------------------------
+// One step of one chain = DFA_ISSUE (where the next slot is: 3 vector instructions and the LDS read)
+// and, after the other chains' steps have covered the read's latency, DFA_RESOLVE (what it says: 11
+// vector, 1 store and 14 scalar instructions on the common path).  The byte never becomes a
+// register of its own: the four instructions that need it select it from the window dword (SDWA).
+// exec is all ones throughout (every lane has a range; ranges are equal).  Per chain: window
+// W0 W1, next piece N0 N1, T slot index, X slot word, L label / LDS address, M the state after a
+// miss.  v20 v21 scratch, v32 stride, v33 0x7f, v34 1; s[38:39] all lanes, s[40:55] scratch:
+//   s[40:41] lanes whose slot lies beyond the LDS array, s[42:43] lanes the global array decides,
+//   s[44:45] miss lanes, s[52:53] lanes whose new event index lies beyond the LDS array.
+// Rare paths, each behind one scalar branch: the global array (lane by lane with scalar loads -- a
+// row beyond LDS: one; a partial row: crow[base], then the slot -- because a vector load's wait would
+// also wait for every store before it), events with an index beyond the LDS array (a counter each
+// instead of the 16-bit stream), arrivals on virtual entries.
+#define DFA_RES_HEAD \
+	".macro DFA_RESOLVE n, w, sel, s, u, t, x, l, m, uc\n"                                              \
+	"  s_waitcnt lgkmcnt(\\n)\n"                                                                        \
+	"  v_bfe_u32 \\l, \\x, 24, %[lbits]\n"
+#define DFA_RES_HIT \
+	"  v_cmp_eq_u32_sdwa vcc, \\w, \\l src0_sel:BYTE_\\sel src1_sel:DWORD\n" /* hit */
+#ifdef DFA_EXP_NOSLOW /* (timing experiment: no lookups beyond LDS; results wrong unless LDS holds everything) */
+#define DFA_RES_SLOWTEST ""
+#define DFA_RES_SLOW "  s_mov_b64 s[52:53], 0\n"
+#else
+#define DFA_RES_SLOWTEST \
+	"  v_cmp_le_u32_e64 s[40:41], %[hot], \\t\n"                                                        \
+	"  v_cmp_gt_i32_e64 s[42:43], 0, \\s\n"             /* the state's LDS row is a partial one */
+#define DFA_RES_SLOW \
+	"  s_andn2_b64 s[42:43], s[42:43], vcc\n"                                                           \
+	"  s_or_b64 s[42:43], s[42:43], s[40:41]\n"                                                         \
+	"  s_mov_b64 s[52:53], 0\n"                                                                         \
+	"  s_cmp_eq_u64 s[42:43], 0\n"                                                                      \
+	"  s_cbranch_scc1 .Lfast%=_\\@\n"                                                                      \
+	"  s_andn2_b64 s[50:51], vcc, s[42:43]\n"           /* ---- the global array decides ---- */        \
+	"  s_mov_b64 s[56:57], s[42:43]\n"                  /* lane by lane, through the scalar cache: a    \
+	                                                       vector load would wait for the stores too */  \
+	".Lwf%=_\\@:\n"                                                                                     \
+	"  s_ff1_i32_b64 s58, s[56:57]\n"                                                                   \
+	"  v_readlane_b32 s59, \\t, s58\n"                  /* slot index (right for a row beyond LDS) */   \
+	"  s_bitcmp1_b64 s[40:41], s58\n"                                                                   \
+	"  s_cbranch_scc1 .Lwc%=_\\@\n"                                                                     \
+	"  v_readlane_b32 s60, \\s, s58\n"                  /* a partial row: crow[base] + code */          \
+	"  v_readlane_b32 s61, \\w, s58\n"                                                                  \
+	"  s_and_b32 s60, s60, 0x7fffff\n"                                                                  \
+	"  s_lshl_b32 s60, s60, 2\n"                                                                        \
+	"  s_load_dword s59, %[crow], s60\n"                                                                \
+	"  s_bfe_u32 s61, s61, (\\sel * 8) | 0x80000\n"                                                     \
+	"  s_waitcnt lgkmcnt(0)\n"                                                                          \
+	"  s_add_u32 s59, s59, s61\n"                                                                       \
+	".Lwc%=_\\@:\n"                                                                                     \
+	"  s_lshl_b32 s60, s59, 2\n"                                                                        \
+	"  s_load_dword s60, %[slot], s60\n"                                                                \
+	"  s_bitset0_b64 s[56:57], s58\n"                                                                   \
+	"  s_mov_b32 m0, s58\n"                            /* (writelane takes one SGPR: the lane comes from m0) */ \
+	"  s_waitcnt lgkmcnt(0)\n"                                                                          \
+	"  v_writelane_b32 \\x, s60, m0\n"                                                                  \
+	"  v_writelane_b32 \\t, s59, m0\n"                                                                 \
+	"  s_cmp_lg_u64 s[56:57], 0\n"                                                                      \
+	"  s_cbranch_scc1 .Lwf%=_\\@\n"                                                                     \
+	"  s_mov_b64 exec, s[42:43]\n"                                                                      \
+	"  v_bfe_u32 \\l, \\x, 24, %[lbits]\n"                                                              \
+	"  v_cmp_eq_u32_sdwa vcc, \\w, \\l src0_sel:BYTE_\\sel src1_sel:DWORD\n"                            \
+	"  s_mov_b64 s[52:53], vcc\n"                       /* their new event index is a global one */     \
+	"  s_or_b64 vcc, vcc, s[50:51]\n"                                                                   \
+	"  s_mov_b64 exec, s[38:39]\n"                                                                      \
+	".Lfast%=_\\@:\n"
+#endif
+#ifdef DFA_EXP_NOLOG /* (timing experiment: no miss events; results wrong) */
+#define DFA_RES_LOG ""
+#else
+#define DFA_RES_LOG \
+	"  s_andn2_b64 s[44:45], s[38:39], vcc\n"           /* ---- the states left by a miss ---- */       \
+	"  s_and_b64 s[46:47], s[44:45], \\uc\n"                                                            \
+	"  s_cbranch_scc0 .Lnocu%=_\\@\n"                                                                      \
+	"  s_mov_b64 exec, s[46:47]\n"                      /* event index beyond LDS: its counter */       \
+	"  v_subrev_u32 v21, %[hot], \\u\n"                                                                 \
+	"  v_lshlrev_b32 v21, 2, v21\n"                                                                     \
+	"  global_atomic_add v21, v34, %[cmiss]\n"                                                          \
+	".Lnocu%=_\\@:\n"                                                                                      \
+	"  s_andn2_b64 exec, s[44:45], \\uc\n"                                                              \
+	"  s_bcnt1_i32_b64 s48, exec\n"                                                                     \
+	"  s_cmp_eq_u32 s48, 0\n"                          /* no lane: lane 0 stores an entry nobody counts, */ \
+	"  s_cselect_b64 exec, 1, exec\n"                  /* so that every step issues one store (vmcnt)   */ \
+	"  v_mbcnt_lo_u32_b32 v20, exec_lo, 0\n"                                                            \
+	"  v_mbcnt_hi_u32_b32 v20, exec_hi, v20\n"          /* rank among them */                           \
+	"  v_lshl_add_u32 v20, v20, 1, %[curm]\n"                                                           \
+	"  global_store_short v20, \\u, %[basem]\n"                                                         \
+	"  s_lshl1_add_u32 %[curm], s48, %[curm]\n"                                                         \
+	"  s_mov_b64 exec, s[38:39]\n"
+#endif
+#ifdef DFA_EXP_NOARR /* (timing experiment: no arrival events; results wrong) */
+#define DFA_RES_ARR ""
+#else
+#define DFA_RES_ARR \
+	"  v_cmp_lt_u32_sdwa s[46:47], v33, \\x src0_sel:DWORD src1_sel:BYTE_2\n" /* kArr */                \
+	"  s_and_b64 s[46:47], s[46:47], vcc\n"             /* ---- arrivals on virtual entries ---- */     \
+	"  s_cbranch_scc0 .Lnoarr%=_\\@\n"                                                                     \
+	"  s_andn2_b64 exec, s[46:47], s[52:53]\n"                                                          \
+	"  v_mbcnt_lo_u32_b32 v20, exec_lo, 0\n"                                                            \
+	"  v_mbcnt_hi_u32_b32 v20, exec_hi, v20\n"                                                          \
+	"  v_lshl_add_u32 v20, v20, 1, %[cura]\n"                                                           \
+	"  global_store_short v20, \\t, %[basea]\n"                                                         \
+	"  s_bcnt1_i32_b64 s48, exec\n"                                                                     \
+	"  s_lshl1_add_u32 %[cura], s48, %[cura]\n"                                                         \
+	"  s_and_b64 exec, s[46:47], s[52:53]\n"                                                            \
+	"  s_cbranch_execz .Larrdone%=_\\@\n"                                                                  \
+	"  v_subrev_u32 v21, %[hot], \\t\n"                                                                 \
+	"  v_lshlrev_b32 v21, 2, v21\n"                                                                     \
+	"  global_atomic_add v21, v34, %[carr]\n"                                                           \
+	".Larrdone%=_\\@:\n"                                                                                   \
+	"  s_mov_b64 exec, s[38:39]\n"                                                                      \
+	".Lnoarr%=_\\@:\n"
+#endif
+#define DFA_RES_TAIL \
+	"  v_mul_u32_u24_sdwa \\m, \\w, v32 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_\\sel src1_sel:DWORD\n" \
+	"  v_cndmask_b32_e32 \\s, \\m, \\x, vcc\n"          /* the next state */                            \
+	"  v_cndmask_b32_sdwa \\u, \\w, \\t, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_\\sel src1_sel:DWORD\n" \
+	"  s_mov_b64 \\uc, s[52:53]\n"                                                                      \
+	".endm\n"
+#define DFA_ASM_MACROS                                                                                  \
+	".macro DFA_ISSUE w, sel, s, t, a, x\n"                                                             \
+	"  v_and_b32 \\t, 0x7fffff, \\s\n"                                                                  \
+	"  v_add_u32_sdwa \\t, \\w, \\t dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_\\sel src1_sel:DWORD\n" \
+	"  v_lshlrev_b32 \\a, 2, \\t\n"                                                                     \
+	"  ds_read_b32 \\x, \\a\n"                                                                          \
+	".endm\n"                                                                                           \
+	DFA_RES_HEAD DFA_RES_SLOWTEST DFA_RES_HIT DFA_RES_SLOW DFA_RES_LOG DFA_RES_ARR DFA_RES_TAIL
+// chain j: W0 W1 N0 N1 T X L M = v[40 + 8 j ...]
+#define DFA_I0(w, sel) "DFA_ISSUE " w ", " #sel ", %[S0], v44, v46, v45\n"
+#define DFA_I1(w, sel) "DFA_ISSUE " w ", " #sel ", %[S1], v52, v54, v53\n"
+#define DFA_I2(w, sel) "DFA_ISSUE " w ", " #sel ", %[S2], v60, v62, v61\n"
+#define DFA_I3(w, sel) "DFA_ISSUE " w ", " #sel ", %[S3], v68, v70, v69\n"
+#define DFA_R0(n, w, sel) "DFA_RESOLVE " #n ", " w ", " #sel ", %[S0], %[U0], v44, v45, v46, v47, %[UC0]\n"
+#define DFA_R1(n, w, sel) "DFA_RESOLVE " #n ", " w ", " #sel ", %[S1], %[U1], v52, v53, v54, v55, %[UC1]\n"
+#define DFA_R2(n, w, sel) "DFA_RESOLVE " #n ", " w ", " #sel ", %[S2], %[U2], v60, v61, v62, v63, %[UC2]\n"
+#define DFA_R3(n, w, sel) "DFA_RESOLVE " #n ", " w ", " #sel ", %[S3], %[U3], v68, v69, v70, v71, %[UC3]\n"
+// one byte of every chain resolved and the next one issued (a*: the window dwords of this byte, b*: of the next)
+#define DFA_K1(a0, sel, b0, seln) DFA_R0(0, a0, sel) DFA_I0(b0, seln)
+#define DFA_K2(a0, a1, sel, b0, b1, seln) DFA_R0(1, a0, sel) DFA_I0(b0, seln) DFA_R1(1, a1, sel) DFA_I1(b1, seln)
+#define DFA_K4(a0, a1, a2, a3, sel, b0, b1, b2, b3, seln)                                               \
+	DFA_R0(3, a0, sel) DFA_I0(b0, seln) DFA_R1(3, a1, sel) DFA_I1(b1, seln) DFA_R2(3, a2, sel) DFA_I2(b2, seln)   \
+	DFA_R3(3, a3, sel) DFA_I3(b3, seln)
+#define DFA_BODY1                                                                                       \
+	DFA_I0("v40", 0) DFA_K1("v40", 0, "v40", 1) DFA_K1("v40", 1, "v40", 2) DFA_K1("v40", 2, "v40", 3)           \
+	DFA_K1("v40", 3, "v41", 0) DFA_K1("v41", 0, "v41", 1) DFA_K1("v41", 1, "v41", 2) DFA_K1("v41", 2, "v41", 3) \
+	DFA_R0(0, "v41", 3)
+#define DFA_BODY2                                                                                       \
+	DFA_I0("v40", 0) DFA_I1("v48", 0)                                                                   \
+	DFA_K2("v40", "v48", 0, "v40", "v48", 1) DFA_K2("v40", "v48", 1, "v40", "v48", 2)                       \
+	DFA_K2("v40", "v48", 2, "v40", "v48", 3) DFA_K2("v40", "v48", 3, "v41", "v49", 0)                       \
+	DFA_K2("v41", "v49", 0, "v41", "v49", 1) DFA_K2("v41", "v49", 1, "v41", "v49", 2)                       \
+	DFA_K2("v41", "v49", 2, "v41", "v49", 3) DFA_R0(1, "v41", 3) DFA_R1(0, "v49", 3)
+#define DFA_BODY4                                                                                       \
+	DFA_I0("v40", 0) DFA_I1("v48", 0) DFA_I2("v56", 0) DFA_I3("v64", 0)                                 \
+	DFA_K4("v40", "v48", "v56", "v64", 0, "v40", "v48", "v56", "v64", 1)                                \
+	DFA_K4("v40", "v48", "v56", "v64", 1, "v40", "v48", "v56", "v64", 2)                                \
+	DFA_K4("v40", "v48", "v56", "v64", 2, "v40", "v48", "v56", "v64", 3)                                \
+	DFA_K4("v40", "v48", "v56", "v64", 3, "v41", "v49", "v57", "v65", 0)                                \
+	DFA_K4("v41", "v49", "v57", "v65", 0, "v41", "v49", "v57", "v65", 1)                                \
+	DFA_K4("v41", "v49", "v57", "v65", 1, "v41", "v49", "v57", "v65", 2)                                \
+	DFA_K4("v41", "v49", "v57", "v65", 2, "v41", "v49", "v57", "v65", 3)                                \
+	DFA_R0(3, "v41", 3) DFA_R1(2, "v49", 3) DFA_R2(1, "v57", 3) DFA_R3(0, "v65", 3)
+// loads of a piece (8 bytes per chain) into the registers W (current) or N (next): chain j at offset 512 j
+#define DFA_LOAD1(r0) "global_load_dwordx2 v[" r0 "], %[voff], %[src]\n"
+#define DFA_LOAD2(r0, r1) DFA_LOAD1(r0) "global_load_dwordx2 v[" r1 "], %[voff], %[src] offset:512\n"
+#define DFA_LOAD4(r0, r1, r2, r3)                                                                       \
+	DFA_LOAD2(r0, r1) "global_load_dwordx2 v[" r2 "], %[voff], %[src] offset:1024\n"                    \
+	                  "global_load_dwordx2 v[" r3 "], %[voff], %[src] offset:1536\n"
+#define DFA_SWAP1 "v_mov_b32 v40, v42\n v_mov_b32 v41, v43\n"
+#define DFA_SWAP2 DFA_SWAP1 "v_mov_b32 v48, v50\n v_mov_b32 v49, v51\n"
+#define DFA_SWAP4 DFA_SWAP2 "v_mov_b32 v56, v58\n v_mov_b32 v57, v59\n v_mov_b32 v64, v66\n v_mov_b32 v65, v67\n"
+// The loop over the pieces of one wave block, from piece p on; left when the pieces are done or a
+// stream batch may not take another piece's events (the C++ around it opens the next batch and
+// comes back).  LOADW / LOADN / BODY / SWAP: the forms above for the number of chains; STEP = 512 * chains.
+#ifdef DFA_EXP_NOLOG
+#define DFA_PIECE_WAIT(STORES) "s_waitcnt vmcnt(0)\n"
+#else
+#define DFA_PIECE_WAIT(STORES) "s_waitcnt vmcnt(" #STORES ")\n" /* (in issue order: the piece came before the body's stores, one per step) */
+#endif
+#define DFA_LOOP(LOADW, LOADN, BODY, SWAP, STEP, STORES)                                                        \
+	DFA_ASM_MACROS                                                                                      \
+	"s_mov_b64 s[38:39], exec\n"                                                                        \
+	"s_mov_b32 s55, m0\n"                               /* (the rare path borrows m0) */                 \
+	"v_mov_b32 v32, %[stride]\n"                                                                        \
+	"v_mov_b32 v33, 0x7f\n"                                                                             \
+	"v_mov_b32 v34, 1\n"                                                                                \
+	LOADW                                                                                               \
+	"s_waitcnt vmcnt(0)\n"                                                                              \
+	".Lpiece%=:\n"                                                                                      \
+	"s_add_u32 s54, %[p], 1\n"                                                                          \
+	"s_cmp_lt_u32 s54, %[pieces]\n"                                                                     \
+	"s_cbranch_scc0 .Lnopf%=\n"                                                                         \
+	"v_add_u32 %[voff], " #STEP ", %[voff]\n"           /* the next piece, under way during this one */ \
+	LOADN                                                                                               \
+	".Lnopf%=:\n"                                                                                       \
+	BODY                                                                                                \
+	DFA_PIECE_WAIT(STORES)                                                                              \
+	SWAP                                                                                                \
+	"s_mov_b32 %[p], s54\n"                                                                             \
+	"s_cmp_ge_u32 %[p], %[pieces]\n"                                                                    \
+	"s_cbranch_scc1 .Lout%=\n"                                                                          \
+	"s_cmp_gt_u32 %[curm], %[high]\n"                                                                   \
+	"s_cbranch_scc1 .Lout%=\n"                                                                          \
+	"s_cmp_gt_u32 %[cura], %[high]\n"                                                                   \
+	"s_cbranch_scc0 .Lpiece%=\n"                                                                        \
+	".Lout%=:\n"                                                                                        \
+	"s_mov_b32 m0, s55\n"                                                                               \
+	"s_mov_b64 exec, s[38:39]\n"                                                                        \
+	".purgem DFA_ISSUE\n"                                                                               \
+	".purgem DFA_RESOLVE\n"
+#define DFA_CLOBBERS                                                                                    \
+	"v20", "v21", "v32", "v33", "v34", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",  \
+	    "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67",    \
+	    "v68", "v69", "v70", "v71", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",    \
+	    "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "vcc", "scc", "memory"
+
+template <int C>
+__global__ void __launch_bounds__(1024) dfa_scan_asm_kernel(DfaDev A, DfaWork W, StreamDev Qm, StreamDev Qa, OutInit I) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t dfa_asm_smem[];
+	LDS_AS uint32_t *img = (LDS_AS uint32_t *)dfa_asm_smem;
+	if (I.out) // (nothing else touches the output vector before this kernel has ended)
+		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < I.V + 5; i += gridDim.x * blockDim.x)
+			I.out[i] = i < 2 ? I.D : (i == I.V + 4 ? I.total_bytes : 0ull);
+	{
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(A.hot);
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)img;
+		for (uint32_t i = threadIdx.x; i < (A.hot_slots + 3) / 4; i += blockDim.x) dst[i] = src[i];
+	}
+	__syncthreads();
+	if ((uint32_t)(uintptr_t)img != 0) {
+		// the loop takes 4 * slot index for an LDS address (the array starts at LDS address 0: this kernel
+		// has no static LDS); reported like a stream overflow, never ignored
+		if (threadIdx.x == 0) Qm.cursor[1] = 1u;
+		return;
+	}
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = uni32(threadIdx.x >> 6);
+	const uint32_t waves = blockDim.x >> 6;
+	const uint32_t wave_id = blockIdx.x * waves + wave;
+	const uint32_t total_waves = gridDim.x * waves;
+	EventLog lm, la;
+	lm.open_own(Qm, wave_id);
+	la.open_own(Qa, wave_id);
+	const uint32_t pieces = uni32(W.range_bytes / 8);
+	const uint32_t hot_slots = uni32(A.hot_slots), lbits = uni32(A.label_bits), stride = A.stride;
+	constexpr uint32_t kHighBytes = (kDfaBatchEntries - 8 * C * 64) * 2;
+	const unsigned long long slot_p = uni64((unsigned long long)(uintptr_t)A.slot), crow_p = uni64((unsigned long long)(uintptr_t)A.crow);
+	const unsigned long long cmiss_p = uni64((unsigned long long)(uintptr_t)W.cold_miss), carr_p = uni64((unsigned long long)(uintptr_t)W.cold_arr);
+
+	for (uint32_t wb = wave_id; wb < W.nwb; wb += total_waves) {
+		uint32_t S[4] = {0, 0, 0, 0}, U[4] = {0, 0, 0, 0};
+		unsigned long long uc[4] = {0, 0, 0, 0}; // lanes whose event index lies beyond the LDS array
+#pragma unroll
+		for (int j = 0; j < C; j++) {
+			const uint2 e = W.entry[(wb * C + j) * 64 + lane];
+			S[j] = e.x, U[j] = e.y;
+			uc[j] = uni64(__builtin_amdgcn_ballot_w64(e.y >= hot_slots));
+		}
+		const unsigned long long src = uni64((unsigned long long)(uintptr_t)(W.tcodes + (size_t)wb * pieces * C * 64));
+		uint32_t p = 0;
+		while (p < pieces) {
+			uint32_t voff = lane * 8 + p * (C * 512);
+			uint32_t curm = uni32(lm.cur * 2), cura = uni32(la.cur * 2);
+			const unsigned long long basem = uni64((unsigned long long)(uintptr_t)lm.base), basea = uni64((unsigned long long)(uintptr_t)la.base);
+			uint32_t pp = uni32(p);
+#define DFA_OPERANDS                                                                                                         \
+	[p] "+s"(pp), [curm] "+s"(curm), [cura] "+s"(cura), [voff] "+v"(voff), [S0] "+v"(S[0]), [U0] "+v"(U[0]), [UC0] "+s"(uc[0]),       \
+	    [S1] "+v"(S[1]), [U1] "+v"(U[1]), [UC1] "+s"(uc[1]), [S2] "+v"(S[2]), [U2] "+v"(U[2]), [UC2] "+s"(uc[2]), [S3] "+v"(S[3]),    \
+	    [U3] "+v"(U[3]), [UC3] "+s"(uc[3])                                                                                            \
+	    : [src] "s"(src), [pieces] "s"(pieces), [hot] "s"(hot_slots), [lbits] "s"(lbits), [high] "s"(kHighBytes),                    \
+	      [basem] "s"(basem), [basea] "s"(basea), [slot] "s"(slot_p), [crow] "s"(crow_p), [cmiss] "s"(cmiss_p),                      \
+	      [carr] "s"(carr_p), [stride] "v"(stride)                                                                                    \
+	    : DFA_CLOBBERS
+			if constexpr (C == 1) {
+				asm volatile(DFA_LOOP(DFA_LOAD1("40:41"), DFA_LOAD1("42:43"), DFA_BODY1, DFA_SWAP1, 512, 8) : DFA_OPERANDS);
+			} else if constexpr (C == 2) {
+				asm volatile(DFA_LOOP(DFA_LOAD2("40:41", "48:49"), DFA_LOAD2("42:43", "50:51"), DFA_BODY2, DFA_SWAP2, 1024, 16) : DFA_OPERANDS);
+			} else {
+				asm volatile(DFA_LOOP(DFA_LOAD4("40:41", "48:49", "56:57", "64:65"), DFA_LOAD4("42:43", "50:51", "58:59", "66:67"),
+				                      DFA_BODY4, DFA_SWAP4, 2048, 32)
+				             : DFA_OPERANDS);
+			}
+#undef DFA_OPERANDS
+			p = pp;
+			lm.cur = curm / 2, la.cur = cura / 2;
+			if (lm.cur * 2 > kHighBytes) lm.roll(Qm, lane);
+			if (la.cur * 2 > kHighBytes) la.roll(Qa, lane);
+		}
+#pragma unroll
+		for (int j = 0; j < C; j++) W.exit_a[(wb * C + j) * 64 + lane] = uint2{S[j] & (kBaseMask | A.inc_bit), U[j]};
 	}
 	lm.close(Qm, lane);
 	la.close(Qa, lane);
@@ -209,18 +513,18 @@ __device__ __forceinline__ void book_event(const DfaDev &A, uint32_t ev, long lo
 	atomicAdd(&out[total_index], (unsigned long long)(n * (long long)len));
 }
 
-// the counters of the slots beyond the LDS prefix; cleared here for the next evaluation
+// the counters of the events beyond the LDS array; cleared here for the next evaluation
 __global__ void __launch_bounds__(256) dfa_cold_reduce_kernel(DfaDev A, uint32_t *cold_miss, uint32_t *cold_arr,
                                                               unsigned long long *out, uint32_t total_index) {
-	const uint32_t n = A.nslots - A.lds_slots;
+	const uint32_t n = A.nslots - A.hot_slots;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t m = cold_miss[i], a = cold_arr[i];
 		if (m) {
-			book_event(A, A.ev_miss[A.lds_slots + i], (long long)m, out, total_index);
+			book_event(A, A.ev_miss[A.hot_slots + i], (long long)m, out, total_index);
 			cold_miss[i] = 0;
 		}
 		if (a) {
-			book_event(A, A.ev_arr[A.lds_slots + i], (long long)a, out, total_index);
+			book_event(A, A.ev_arr[A.hot_slots + i], (long long)a, out, total_index);
 			cold_arr[i] = 0;
 		}
 	}
@@ -241,12 +545,26 @@ struct DfaFix {
 };
 
 __device__ __forceinline__ void dfa_step_global(const DfaFix &F, uint32_t &S, uint32_t &U, uint32_t c, long long sign) {
-	const uint32_t t = (S & kBaseMask) + c;
-	const uint32_t x = F.A.slot[t];
-	if ((x >> kLabelShift) == c) {
-		if (x & kArr) book_event(F.A, F.A.ev_arr[t], sign, F.out, F.total_index);
-		S = x & 0xFFFFFFu;
-		U = t;
+	const uint32_t lmask = (1u << F.A.label_bits) - 1;
+	const uint32_t b = S & kBaseMask, t = b + c;
+	uint32_t x, id = t;
+	bool hit;
+	if (t < F.A.hot_slots) {
+		x = F.A.hot[t];
+		hit = ((x >> 24) & lmask) == c;
+		if (!hit && (S & F.A.inc_bit) != 0) {
+			id = F.A.crow[b] + c;
+			x = F.A.slot[id];
+			hit = ((x >> 24) & lmask) == c;
+		}
+	} else {
+		x = F.A.slot[t];
+		hit = ((x >> 24) & lmask) == c;
+	}
+	if (hit) {
+		if (x & kArr) book_event(F.A, F.A.ev_arr[id], sign, F.out, F.total_index);
+		S = x & (kBaseMask | F.A.inc_bit);
+		U = id;
 	} else {
 		book_event(F.A, F.A.ev_miss[U], sign, F.out, F.total_index);
 		S = c * F.A.stride;
@@ -256,7 +574,8 @@ __device__ __forceinline__ void dfa_step_global(const DfaFix &F, uint32_t &S, ui
 
 // true when the two automata met inside the range (its exit stands); *exit_out = the true one's state at the end
 __device__ bool dfa_dual_walk(const DfaFix &F, uint32_t g, uint2 want, uint2 have, uint2 *exit_out) {
-	uint32_t Sa = want.x & 0xFFFFFFu, Ua = want.y, Sb = have.x & 0xFFFFFFu, Ub = have.y;
+	const uint32_t keep = kBaseMask | F.A.inc_bit;
+	uint32_t Sa = want.x & keep, Ua = want.y, Sb = have.x & keep, Ub = have.y;
 	const uint8_t *p = F.codes + (size_t)g * F.range_bytes;
 	for (uint32_t i = 0; i < F.range_bytes; i++) {
 		if (Sa == Sb && Ua == Ub) return true;
@@ -371,10 +690,22 @@ void launch_dfa_scan(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, con
 			                      0u, A, W, Qm, Qa, init);
 		else hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, A, W, Qm, Qa, init);
 	};
-	switch (plan.chains) {
-	case 1: go(&dfa_scan_kernel<1>); break;
-	case 2: go(&dfa_scan_kernel<2>); break;
-	default: go(&dfa_scan_kernel<4>); break;
+	static const bool use_asm = [] {
+		const char *e = getenv("TOKSCORE_ASM");
+		return !(e && atoi(e) == 0);
+	}();
+	if (use_asm) {
+		switch (plan.chains) {
+		case 1: go(&dfa_scan_asm_kernel<1>); break;
+		case 2: go(&dfa_scan_asm_kernel<2>); break;
+		default: go(&dfa_scan_asm_kernel<4>); break;
+		}
+	} else {
+		switch (plan.chains) {
+		case 1: go(&dfa_scan_kernel<1>); break;
+		case 2: go(&dfa_scan_kernel<2>); break;
+		default: go(&dfa_scan_kernel<4>); break;
+		}
 	}
 }
 
@@ -387,14 +718,14 @@ void launch_dfa_fixup(const DfaDev &A, const DfaWork &W, const uint8_t *codes, u
 }
 
 void launch_dfa_cold_reduce(const DfaDev &A, const DfaWork &W, unsigned long long *out, uint32_t total_index, hipStream_t stream) {
-	const uint32_t n = A.nslots - A.lds_slots;
+	const uint32_t n = A.nslots - A.hot_slots;
 	if (n == 0) return;
 	hipLaunchKernelGGL(dfa_cold_reduce_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 2048)), dim3(256), 0, stream, A, W.cold_miss,
 	                   W.cold_arr, out, total_index);
 }
 
-bool plan_dfa_scan(uint32_t nslots, uint64_t prep_total, uint32_t num_cus, uint32_t chains_hint, uint32_t lds_cap, DfaScanPlan *plan) {
-	plan->lds_slots = std::min<uint32_t>(nslots, dfa_lds_slots_max(lds_cap));
+bool plan_dfa_scan(uint32_t hot_slots, uint64_t prep_total, uint32_t num_cus, uint32_t chains_hint, DfaScanPlan *plan) {
+	plan->lds_slots = hot_slots;
 	plan->lds_bytes = ((plan->lds_slots + 3) & ~3u) * 4;
 	plan->blocks = num_cus;
 	plan->waves_per_block = 16;

@@ -23,15 +23,22 @@ using namespace tokscore;
 namespace {
 
 constexpr uint64_t kCorpusPad = 4096;         // readable zero bytes past the corpus end (tile halo)
-constexpr uint64_t kSampleBytes = 2u << 20;   // host sample for the hot-first trie layout
 constexpr uint64_t kSamplePieces = 16;
 constexpr size_t kMaxPatch = 8;               // toggles an incremental re-score takes in one go
+
+uint64_t env_u64_early(const char *name, uint64_t dflt) {
+	const char *s = getenv(name);
+	if (!s || !*s) return dflt;
+	return strtoull(s, nullptr, 10);
+}
 
 uint64_t env_u64(const char *name, uint64_t dflt) {
 	const char *s = getenv(name);
 	if (!s || !*s) return dflt;
 	return strtoull(s, nullptr, 10);
 }
+
+const uint64_t kSampleBytes = std::max<uint64_t>(1, env_u64_early("TOKSCORE_SAMPLE_MB", 2)) << 20; // host sample for the hot-first layouts
 
 // interval between two recorded events; 0 when both are the same event
 hipError_t elapsed_ms(float *ms, hipEvent_t a, hipEvent_t b) {
@@ -233,7 +240,7 @@ struct tokscore_ctx {
 	uint32_t dfa_chains = 0;
 	uint32_t dfa_lds_cap = 0;
 	DfaScanPlan dplan = {};
-	uint32_t *d_dslot = nullptr, *d_dev_miss = nullptr, *d_dev_arr = nullptr, *d_dpool = nullptr;
+	uint32_t *d_dhot = nullptr, *d_dcrow = nullptr, *d_dslot = nullptr, *d_dev_miss = nullptr, *d_dev_arr = nullptr, *d_dpool = nullptr;
 	uint8_t *d_dcodes = nullptr;   // the prepared corpus in the automaton's codes, linear
 	void *d_dtcodes = nullptr;     // ... transposed for the scan
 	uint2 *d_dstate = nullptr;     // entry | exit_a | exit_b
@@ -333,7 +340,7 @@ int build_prepared(tokscore_ctx *c) {
 }
 
 void free_dfa(tokscore_ctx *c) {
-	void **bufs[] = {(void **)&c->d_dslot, (void **)&c->d_dev_miss, (void **)&c->d_dev_arr, (void **)&c->d_dpool, (void **)&c->d_dcodes,
+	void **bufs[] = {(void **)&c->d_dhot, (void **)&c->d_dcrow, (void **)&c->d_dslot, (void **)&c->d_dev_miss, (void **)&c->d_dev_arr, (void **)&c->d_dpool, (void **)&c->d_dcodes,
 	                 &c->d_dtcodes, (void **)&c->d_dstate, (void **)&c->d_dtag, (void **)&c->d_dcold, &c->d_dstream_m, &c->d_dstream_a,
 	                 (void **)&c->d_dfill_m, (void **)&c->d_dfill_a, (void **)&c->d_dcursor, (void **)&c->d_dslab};
 	for (void **b : bufs) {
@@ -842,6 +849,7 @@ int ensure_plan(tokscore_ctx *c) {
 bool upload_dfa_image(tokscore_ctx *c) {
 	DfaOptions opt;
 	opt.max_slots = c->dfa_max_slots;
+	opt.lds_slots = dfa_lds_slots_max(c->dfa_lds_cap);
 	opt.sample = c->sample.empty() ? nullptr : c->sample.data();
 	opt.sample_bytes = c->sample.size();
 	std::string why;
@@ -849,19 +857,23 @@ bool upload_dfa_image(tokscore_ctx *c) {
 	if (!c->trie.BuildDfa(&c->dimg, opt, &why)) return false;
 	c->dfa_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	const DfaImage &g = c->dimg;
-	const size_t n = g.nslots;
-	for (uint32_t **b : {&c->d_dslot, &c->d_dev_miss, &c->d_dev_arr, &c->d_dpool}) {
+	const size_t n = g.nslots, nh = g.hot_slots, ne = g.ev_miss.size();
+	for (uint32_t **b : {&c->d_dhot, &c->d_dcrow, &c->d_dslot, &c->d_dev_miss, &c->d_dev_arr, &c->d_dpool}) {
 		if (*b) (void)hipFree(*b);
 		*b = nullptr;
 	}
-	bool ok = hipMalloc((void **)&c->d_dslot, (n + 16) * sizeof(uint32_t)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_dev_miss, (n + 16) * sizeof(uint32_t)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_dev_arr, (n + 16) * sizeof(uint32_t)) == hipSuccess &&
+	bool ok = hipMalloc((void **)&c->d_dhot, (nh + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dcrow, (nh + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dslot, (n + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dev_miss, (ne + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dev_arr, (ne + 16) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dpool, (g.pool.size() + 16) * sizeof(uint32_t)) == hipSuccess;
-	ok = ok && hipMemsetAsync(c->d_dslot + n, 0xFF, 16 * sizeof(uint32_t), c->stream) == hipSuccess &&
+	ok = ok && hipMemsetAsync(c->d_dhot + nh, 0xFF, 16 * sizeof(uint32_t), c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dhot, g.hot.data(), nh * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dcrow, g.crow.data(), nh * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
 	     hipMemcpyAsync(c->d_dslot, g.slot.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-	     hipMemcpyAsync(c->d_dev_miss, g.ev_miss.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-	     hipMemcpyAsync(c->d_dev_arr, g.ev_arr.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dev_miss, g.ev_miss.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dev_arr, g.ev_arr.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
 	     (g.pool.empty() || hipMemcpyAsync(c->d_dpool, g.pool.data(), g.pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess) &&
 	     hipStreamSynchronize(c->stream) == hipSuccess;
 	if (!ok) (void)hipGetLastError();
@@ -870,9 +882,11 @@ bool upload_dfa_image(tokscore_ctx *c) {
 
 DfaDev dfa_dev(const tokscore_ctx *c) {
 	DfaDev A;
-	A.slot = c->d_dslot, A.ev_miss = c->d_dev_miss, A.ev_arr = c->d_dev_arr, A.pool = c->d_dpool;
+	A.hot = c->d_dhot, A.crow = c->d_dcrow, A.slot = c->d_dslot, A.ev_miss = c->d_dev_miss, A.ev_arr = c->d_dev_arr, A.pool = c->d_dpool;
 	A.nslots = c->dimg.nslots;
-	A.lds_slots = std::min<uint32_t>(c->dplan.lds_slots, c->dimg.nslots);
+	A.hot_slots = c->dimg.hot_slots;
+	A.label_bits = c->dimg.label_bits;
+	A.inc_bit = c->dimg.inc_bit;
 	A.stride = c->dimg.stride;
 	return A;
 }
@@ -888,7 +902,7 @@ DfaWork dfa_work(const tokscore_ctx *c) {
 	W.exit_b = c->d_dstate + 2 * (size_t)W.nranges;
 	W.exit_tag = c->d_dtag;
 	W.cold_miss = c->d_dcold;
-	W.cold_arr = c->d_dcold + (c->dimg.nslots - std::min<uint32_t>(c->dplan.lds_slots, c->dimg.nslots)) + 1;
+	W.cold_arr = c->d_dcold + c->dimg.nslots + 1;
 	return W;
 }
 
@@ -902,11 +916,11 @@ void ensure_dfa(tokscore_ctx *c) {
 	const auto t0 = std::chrono::steady_clock::now();
 	if (!upload_dfa_image(c)) return;
 	DfaScanPlan &P = c->dplan;
-	if (!plan_dfa_scan(c->dimg.nslots, prep_total, (uint32_t)c->num_cus, c->dfa_chains, c->dfa_lds_cap, &P)) return;
+	if (!plan_dfa_scan(c->dimg.hot_slots, prep_total, (uint32_t)c->num_cus, c->dfa_chains, &P)) return;
 	const uint64_t nranges = (uint64_t)P.nwb * 64 * P.chains;
 	const uint64_t covered = nranges * P.range_bytes; // >= prep_total: the rest reads as separators
 	const uint64_t lin_bytes = std::max<uint64_t>(covered, prep_total) + kCorpusPad;
-	const uint32_t ncold = c->dimg.nslots - std::min<uint32_t>(P.lds_slots, c->dimg.nslots);
+	const uint32_t ncold = c->dimg.nslots;
 	c->dstream_cap = 0;
 	const uint64_t cap = dfa_stream_capacity_batches(P);
 	if (cap > 0x7FFFFFF0ull) return;
@@ -961,7 +975,7 @@ bool refresh_dfa(tokscore_ctx *c) {
 	const uint32_t old_codes = c->dimg.ncodes;
 	if (!upload_dfa_image(c) || c->dimg.ncodes != old_codes) return false;
 	DfaScanPlan P = c->dplan;
-	const uint32_t lds = std::min<uint32_t>(dfa_lds_slots_max(c->dfa_lds_cap), c->dimg.nslots);
+	const uint32_t lds = c->dimg.hot_slots;
 	// (the cold counters and the slab are sized by the image)
 	if (c->d_dcold) (void)hipFree(c->d_dcold);
 	if (c->d_dslab) (void)hipFree(c->d_dslab);
@@ -969,7 +983,7 @@ bool refresh_dfa(tokscore_ctx *c) {
 	P.lds_slots = lds;
 	P.lds_bytes = ((lds + 3) & ~3u) * 4;
 	c->dplan = P;
-	const uint32_t ncold = c->dimg.nslots - lds;
+	const uint32_t ncold = c->dimg.nslots;
 	bool ok = hipMalloc((void **)&c->d_dcold, (2 * (size_t)ncold + 2) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dslab, (size_t)c->dslab_blocks * (P.lds_slots + 2) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMemsetAsync(c->d_dcold, 0, (2 * (size_t)ncold + 2) * sizeof(uint32_t), c->stream) == hipSuccess &&
@@ -1072,8 +1086,8 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		launch_dfa_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Qm, Qa, c->dplan.blocks * c->dplan.waves_per_block, c->d_dcursor + 8, s);
 		launch_dfa_scan(A, W, Qm, Qa, c->dplan, s, OutInit{d_out, (uint32_t)c->V, c->D, c->total}, ev ? ev[1] : nullptr, ev ? ev[2] : nullptr);
 		launch_dfa_fixup(A, W, c->d_dcodes, c->d_dcursor + 8, ++c->dfa_epoch, d_out, (uint32_t)c->V + 3, s);
-		launch_histogram_events(Qm, A.lds_slots, c->d_dev_miss, c->d_dpool, d_out, (uint32_t)c->V + 3, c->d_dslab, c->dslab_blocks, s);
-		launch_histogram_events(Qa, A.lds_slots, c->d_dev_arr, c->d_dpool, d_out, (uint32_t)c->V + 3, c->d_dslab, c->dslab_blocks, s);
+		launch_histogram_events(Qm, A.hot_slots, c->d_dev_miss, c->d_dpool, d_out, (uint32_t)c->V + 3, c->d_dslab, c->dslab_blocks, s);
+		launch_histogram_events(Qa, A.hot_slots, c->d_dev_arr, c->d_dpool, d_out, (uint32_t)c->V + 3, c->d_dslab, c->dslab_blocks, s);
 		launch_dfa_cold_reduce(A, W, d_out, (uint32_t)c->V + 3, s);
 	} else if (c->scan_path == 2) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
@@ -2231,12 +2245,13 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 	info->base_scan_path = info->scan_path;
 	if (c->plan_valid && c->dfa_state == 1) {
 		info->dfa_slots = c->dimg.nslots;
-		info->dfa_lds_slots = std::min<uint32_t>(c->dplan.lds_slots, c->dimg.nslots);
+		info->dfa_lds_slots = c->dimg.hot_slots;
+		info->dfa_lds_used = c->dimg.hot_used;
 		info->dfa_virtual_slots = c->dimg.virtual_slots;
 		info->dfa_active = c->dfa_used_last ? 1u : 0u;
 		info->dfa_chains = c->dplan.chains;
 		info->dfa_range_bytes = c->dplan.range_bytes;
-		info->dfa_hot_fraction = c->dimg.hot_fraction(info->dfa_lds_slots);
+		info->dfa_hot_fraction = c->dimg.hot_fraction();
 		info->dfa_build_ms = c->dfa_build_ms;
 		info->dfa_plan_ms = c->dfa_plan_ms;
 		if (c->dfa_used_last) info->scan_path = 2;
@@ -2303,20 +2318,22 @@ int tokscore_hosttrie_longest(tokscore_ctx *c, const uint8_t *text, uint64_t n, 
 }
 
 int tokscore_hostdfa_check(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t max_slots,
-                           uint64_t *counts, uint64_t *total_tokens, uint64_t stats[8]) {
+                           uint32_t lds_slots, uint64_t *counts, uint64_t *total_tokens, uint64_t stats[8]) {
 	if (!c || !off || !counts || !total_tokens || (!bytes && D && off[D] != off[0])) return TOKSCORE_E_ARG;
 	if (!c->vocab_set) return fail(c, TOKSCORE_E_STATE, "vocabulary not set");
 	DfaImage img;
 	DfaOptions opt;
 	if (max_slots) opt.max_slots = max_slots;
+	if (lds_slots) opt.lds_slots = lds_slots;
 	opt.sample = bytes ? bytes + off[0] : nullptr;
 	opt.sample_bytes = std::min<uint64_t>(off[D] - off[0], kSampleBytes);
 	std::string why;
 	if (!c->trie.BuildDfa(&img, opt, &why)) return fail(c, TOKSCORE_E_VOCAB, why);
-	DfaRun(img, bytes, off, D, c->V, counts, total_tokens);
+	uint64_t global_reads = 0;
+	DfaRun(img, bytes, off, D, c->V, counts, total_tokens, &global_reads);
 	if (stats) {
 		stats[0] = img.nslots, stats[1] = img.real_slots, stats[2] = img.virtual_slots, stats[3] = img.ncodes;
-		stats[4] = img.stride, stats[5] = img.max_events, stats[6] = img.sample_steps, stats[7] = img.sample_virtual;
+		stats[4] = img.hot_used, stats[5] = global_reads, stats[6] = img.sample_steps, stats[7] = img.sample_virtual;
 	}
 	return TOKSCORE_OK;
 }
