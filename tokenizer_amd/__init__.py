@@ -33,7 +33,8 @@ class TokscoreInfo(C.Structure):
                 ("toggle_streams", C.c_uint64), ("dfa_slots", C.c_uint64), ("dfa_virtual_slots", C.c_uint64),
                 ("dfa_lds_slots", C.c_uint32), ("dfa_active", C.c_uint32), ("dfa_chains", C.c_uint32),
                 ("dfa_range_bytes", C.c_uint32), ("base_scan_path", C.c_uint32), ("dfa_lds_used", C.c_uint32),
-                ("dfa_hot_fraction", C.c_double), ("dfa_build_ms", C.c_double), ("dfa_plan_ms", C.c_double)]
+                ("dfa_hot_fraction", C.c_double), ("dfa_build_ms", C.c_double), ("dfa_plan_ms", C.c_double),
+                ("dfa_second_hits", C.c_uint64), ("dfa_relayouts", C.c_uint32), ("dfa_reserved", C.c_uint32)]
 
 
 # every symbol include/tokscore.h declares: (name, restype, argtypes)

@@ -2,6 +2,7 @@
 #include "dfa.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -53,7 +54,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	uint32_t k = 0;
 	for (uint32_t b = 1; b < 256; b++) k += is_label[b] ? 1 : 0;
 	const uint32_t ncodes = k + 2;
-	if (ncodes > DfaImage::kMaxCodes) return fail("too many distinct edge bytes");
+	if (ncodes > DfaImage::kMaxCodes) return fail("too many distinct edge bytes (the label has 7 bits)");
 	const uint32_t other = k + 1;
 	{
 		uint32_t next = 1;
@@ -217,7 +218,8 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	};
 	// ---- hotness: the sample run through the automaton (document boundaries ignored: layout only) ----
 	std::vector<uint64_t> w_row(S, 0);
-	std::vector<uint32_t> w_ent(ent.size(), 0), w_d1(ncodes, 0);
+	std::vector<uint64_t> w_ent(ent.size(), 0);
+	std::vector<uint32_t> w_d1(ncodes, 0);
 	out->sample_steps = out->sample_virtual = out->sample_miss = 0;
 	if (opt.sample && opt.sample_bytes) {
 		uint32_t st = d1[0];
@@ -242,63 +244,110 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			}
 		}
 	}
+	const bool sampled = out->sample_steps != 0;
+	// what an earlier image counted on the whole corpus: uses of entries LDS did not hold.  The sample's
+	// counts are brought to the corpus's scale first, so that the two can be compared.
+	if (opt.prior && opt.prior_entries == ent.size()) {
+		if (sampled && opt.corpus_bytes > opt.sample_bytes) {
+			const uint64_t scale = opt.corpus_bytes / opt.sample_bytes;
+			for (auto &w : w_row) w *= scale;
+			for (auto &w : w_ent) w *= scale;
+		}
+		for (uint32_t s = 1; s < S; s++)
+			for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) {
+				if (!opt.prior[j]) continue;
+				w_ent[j] += opt.prior[j];
+				w_row[s] += opt.prior[j];
+				w_row[ent[j].target] += opt.prior[j];
+			}
+	}
+	const bool weighted = sampled || (opt.prior && opt.prior_entries == ent.size());
 	// ---- which entries and rows are worth LDS ----
 	// The global array holds the whole automaton: every row complete, beyond hot_cap.  The LDS array
-	// is an overlay for the rows the sample visited, the rows with the most lookups per LDS entry
-	// first, for as long as entries fit: a row is there COMPLETE, or PARTIAL -- only the entries the
-	// sample used; a miss in a partial row proves nothing, so it is looked up again in the row's
-	// complete copy -- whichever is worth the slots: the rows with the most misses per unused entry
-	// are completed while slots are left.
-	const uint32_t hot_cap = std::max<uint32_t>(opt.lds_slots, 2 * ncodes + 64);
-	const bool sampled = out->sample_steps != 0;
-	const bool can_split = ncodes <= 127; // (with more codes the label takes the bit that marks a partial row)
+	// is an overlay for the rows in use, the rows with the most lookups per LDS entry first, for as
+	// long as entries fit: a row is there COMPLETE, or PARTIAL -- only the entries in use; a miss in a
+	// partial row proves nothing, so it is looked up again in the row's complete copy -- whichever is
+	// worth the slots: the rows with the most misses per unused entry are completed while slots are left.
+	const uint32_t hot_cap = std::min<uint32_t>(std::max<uint32_t>(opt.lds_slots, 2 * ncodes + 64), DfaImage::kMaxHot);
 	std::vector<uint32_t> nhot(S, 0), ncold(S, 0);
-	std::vector<uint64_t> w_miss(S, 0);
+	std::vector<uint64_t> w_miss(S, 0); // lookups of a row that miss
 	std::vector<uint8_t> is_d1(S, 0), klass(S, 0); // klass: 0 global array only, 1 complete in LDS, 2 partial in LDS
+	std::vector<uint8_t> sel(ent.size(), 0);       // the entry is one of those a partial row keeps in LDS
 	for (uint32_t c = 0; c < ncodes; c++) is_d1[d1[c]] = 1;
-	if (!sampled) { // no sample: breadth-first, everything counts as used
+	if (!weighted) { // nothing to go by: breadth-first, everything counts as used
 		for (uint32_t s = 1; s < N; s++) w_row[s] = 1 + (max_len_ + 1 - std::min<uint64_t>(depth_[s], max_len_ + 1));
 		std::fill(w_ent.begin(), w_ent.end(), 1u);
 	}
+	std::vector<uint32_t> owner(ent.size(), 0);
 	for (uint32_t s = 1; s < S; s++) {
 		uint64_t used_sum = 0;
-		for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) {
-			if (w_ent[j] || is_d1[s]) nhot[s]++;
-			else ncold[s]++;
-			used_sum += w_ent[j];
-		}
-		w_miss[s] = sampled && w_row[s] > used_sum ? w_row[s] - used_sum : 0;
+		for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) owner[j] = s, used_sum += w_ent[j];
+		w_miss[s] = weighted && w_row[s] > used_sum ? w_row[s] - used_sum : 0;
 	}
 	uint64_t d1_slots = ncodes;
 	for (uint32_t c = 1; c < ncodes; c++) d1_slots += row_off[d1[c] + 1] - row_off[d1[c]];
-	std::vector<uint32_t> order; // LDS candidates, best first
-	for (uint32_t s = 1; s < S; s++) {
-		if (is_d1[s] || row_off[s + 1] == row_off[s] || w_row[s] == 0) continue;
-		order.push_back(s);
-	}
 	{
-		auto cost = [&](uint32_t s) { return can_split ? std::max<uint32_t>(1, nhot[s]) : nhot[s] + ncold[s]; };
-		auto value = [&](uint32_t s) { return (double)w_row[s] / (double)cost(s); };
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return value(a) > value(b); });
+		// What a slot of LDS saves is second looks: an entry kept there saves its uses, the slots that complete
+		// a row save the row's misses and the uses of the entries they add (a miss in a partial row is looked up
+		// again, a miss in a complete one is a miss).  Everything that saves at least `th` lookups per slot goes
+		// in, for the smallest th that fits (first-fit leaves holes: some slack); entries fill what is left.
+		std::vector<uint64_t> cand;
+		for (uint64_t j = 0; j < ent.size(); j++) {
+			if (is_d1[owner[j]]) sel[j] = 1;
+			else if (w_ent[j]) cand.push_back(j);
+		}
+		std::stable_sort(cand.begin(), cand.end(), [&](uint64_t a, uint64_t b) { return w_ent[a] > w_ent[b]; });
 		const double room = hot_cap > d1_slots + 2 * ncodes ? (double)(hot_cap - d1_slots - 2 * ncodes) : 0.0;
-		double taken = 0;
-		std::vector<uint32_t> partial;
-		for (uint32_t s : order) {
-			if (taken + cost(s) > 0.95 * room) break; // (slack: first-fit leaves holes)
-			taken += cost(s);
-			klass[s] = can_split && ncold[s] ? 2 : 1;
-			if (klass[s] == 2) partial.push_back(s);
+		auto choose = [&](double th, bool apply) -> double {
+			double slots = 0;
+			for (uint32_t s = 1; s < S; s++) {
+				if (is_d1[s] || row_off[s + 1] == row_off[s]) continue;
+				uint32_t n_in = 0, n_out = 0;
+				uint64_t w_un = 0;
+				for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) {
+					if (w_ent[j] && (double)w_ent[j] >= th) n_in++;
+					else n_out++, w_un += w_ent[j];
+				}
+				const bool complete = n_out != 0 && w_miss[s] + w_un != 0 && (double)(w_miss[s] + w_un) / n_out >= th;
+				slots += complete ? n_in + n_out : n_in;
+				if (apply)
+					for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) sel[j] = complete || (w_ent[j] && (double)w_ent[j] >= th);
+			}
+			return slots;
+		};
+		double lo = 0.25, hi = 1;
+		for (uint64_t j : cand) hi = std::max(hi, (double)w_ent[j] + 1);
+		for (uint32_t s = 1; s < S; s++) hi = std::max(hi, (double)w_miss[s] + 1);
+		if (choose(lo, false) > 0.97 * room) {
+			for (int it = 0; it < 48 && hi - lo > 1e-3 * lo; it++) {
+				const double mid = std::sqrt(lo * hi);
+				if (choose(mid, false) > 0.97 * room) lo = mid;
+				else hi = mid;
+			}
+			lo = hi;
 		}
-		std::stable_sort(partial.begin(), partial.end(), [&](uint32_t a, uint32_t b) {
-			return (double)w_miss[a] / ncold[a] > (double)w_miss[b] / ncold[b];
-		});
-		for (uint32_t s : partial) {
-			if (w_miss[s] == 0) break;
-			if (taken + ncold[s] > 0.995 * room) continue;
-			taken += ncold[s];
-			klass[s] = 1;
+		double taken = choose(lo, true);
+		auto count_row = [&](uint32_t s) {
+			nhot[s] = ncold[s] = 0;
+			for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) {
+				if (sel[j]) nhot[s]++;
+				else ncold[s]++;
+			}
+			klass[s] = nhot[s] ? (ncold[s] ? 2 : 1) : 0;
+		};
+		for (uint64_t j : cand) {
+			if (taken + 1 > 0.985 * room) break;
+			if (!sel[j]) sel[j] = 1, taken++;
 		}
+		for (uint32_t s = 1; s < S; s++)
+			if (!is_d1[s] && row_off[s + 1] != row_off[s]) count_row(s);
 	}
+	std::vector<uint32_t> order; // rows with slots in LDS, in the order they are placed: the most lookups per slot first
+	for (uint32_t s = 1; s < S; s++)
+		if (!is_d1[s] && klass[s] != 0) order.push_back(s);
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+		return (double)w_row[a] / std::max<uint32_t>(1, nhot[a]) > (double)w_row[b] / std::max<uint32_t>(1, nhot[b]);
+	});
 	// ---- placement ----
 	struct Occ {
 		std::vector<uint8_t> used, base_used;
@@ -343,12 +392,23 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			ensure(b + 1);
 			base_used[b] = 1;
 		}
+		// a base for a state that stores nothing: any value of its own, at or after lo (0: none below hi)
+		uint64_t fresh_base(uint64_t lo, uint64_t hi) {
+			uint64_t b = std::max<uint64_t>(lo, base_cursor);
+			while (base_taken(b)) b++;
+			if (hi && b >= hi) return 0;
+			base_cursor = b + 1;
+			take_base(b);
+			max_base = std::max(max_base, b);
+			return b;
+		}
 		uint64_t max_used = 0, max_base = 0, base_cursor = 1;
 	};
 	Occ H, G; // the LDS array [0, hot_cap) and the global array [hot_cap, ...): bases are unique within each
 	std::vector<uint32_t> base_h(S, 0), base_g(S, 0);
 	// the root row: dense at base 0, slot c = the depth-1 state of code c
 	for (uint32_t c = 0; c < ncodes; c++) H.take(c);
+	H.take_base(0);
 	// depth-1 rows at c * stride: the smallest stride whose occupied slots are all different and clear of the root row
 	uint32_t stride = 0;
 	{
@@ -367,33 +427,29 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 		if (!stride) stride = ncodes; // (always fits: rows then do not overlap at all)
 	}
 	if ((uint64_t)(ncodes - 1) * stride + ncodes > hot_cap) return fail("the depth-1 rows do not fit the LDS array");
+	std::vector<uint8_t> has_id(S, 0); // the state has an LDS base of its own
+	std::vector<uint8_t> in_lds(S, 0); // its row has slots in LDS: 1 every entry, 2 the entries in use
 	for (uint32_t c = 0; c < ncodes; c++) {
 		base_h[d1[c]] = c * stride;
 		klass[d1[c]] = 1;
+		has_id[d1[c]] = 1;
+		in_lds[d1[c]] = 1;
 		H.take_base(c * stride);
 		if (c == 0) continue;
 		for (uint64_t j = row_off[d1[c]]; j < row_off[d1[c] + 1]; j++) H.take(c * stride + ent[j].code);
 	}
-	// the base of states without a row: a value no state has, so no slot "belongs" to it
-	uint32_t empty_base = 1;
-	while (H.base_taken(empty_base)) empty_base++;
-	H.take_base(empty_base);
 	// A row into occupancy `occ` with bases in [lo, hi) (hi = 0: no upper limit); only_used: just the
-	// entries the sample used.  False when nothing fits below hi.
+	// entries in use.  False when nothing fits below hi.
 	const uint64_t slot_limit = std::min<uint64_t>(opt.max_slots, DfaImage::kMaxSlots);
 	auto place = [&](Occ &occ, uint32_t s, bool only_used, uint64_t lo, uint64_t hi, uint32_t *base_out) -> bool {
 		const Entry *e = ent.data() + row_off[s];
 		const uint32_t nc = (uint32_t)(row_off[s + 1] - row_off[s]);
-		auto in = [&](uint32_t i) { return !only_used || w_ent[row_off[s] + i] != 0; };
+		auto in = [&](uint32_t i) { return !only_used || sel[row_off[s] + i] != 0; };
 		uint32_t lead = 0;
 		while (lead < nc && !in(lead)) lead++;
-		if (lead == nc) { // nothing to store (a partial row none of whose entries was used): any base of its own
-			uint64_t b = std::max<uint64_t>(lo, occ.base_cursor);
-			while (occ.base_taken(b)) b++;
-			if (hi && b >= hi) return false;
-			occ.base_cursor = b + 1;
-			occ.take_base(b);
-			occ.max_base = std::max(occ.max_base, b);
+		if (lead == nc) { // nothing to store (a partial row none of whose entries is in use): any base of its own
+			const uint64_t b = occ.fresh_base(lo, hi);
+			if (!b) return false;
 			*base_out = (uint32_t)b;
 			return true;
 		}
@@ -431,43 +487,93 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	for (uint32_t s : order) {
 		if (klass[s] == 0) continue;
 		n_sel++;
-		if (klass[s] == 1 && !place(H, s, false, 1, hot_hi, &base_h[s])) klass[s] = can_split && ncold[s] ? 2 : 0;
+		if (klass[s] == 1 && !place(H, s, false, 1, hot_hi, &base_h[s])) klass[s] = ncold[s] ? 2 : 0;
 		if (klass[s] == 2 && !place(H, s, true, 1, hot_hi, &base_h[s])) klass[s] = 0;
 		n_demoted += klass[s] == 0;
+		has_id[s] = klass[s] != 0;
+		in_lds[s] = klass[s];
 	}
-	// the whole automaton in the global array (the depth-1 rows excepted: they are complete in LDS)
+	// the base the states without one of their own share: a value no state has, so no slot "belongs" to it
+	uint32_t cold_base = 1;
+	while (H.base_taken(cold_base)) cold_base++;
+	H.take_base(cold_base);
+	// every other state: a base of its own while values last -- the states in use first
+	uint32_t n_cold = 0;
+	{
+		// (the states the depth-1 rows lead to come first: the state after a miss is computed, c * stride, with
+		// no word to say "partial", so those rows must be complete in LDS, which takes a base for every target)
+		std::vector<uint8_t> must(S, 0);
+		for (uint32_t c = 1; c < ncodes; c++)
+			for (uint64_t j = row_off[d1[c]]; j < row_off[d1[c] + 1]; j++) must[ent[j].target] = 1;
+		std::vector<uint32_t> rest;
+		for (uint32_t s = 1; s < S; s++)
+			if (!has_id[s] && (s >= N || reach[s])) rest.push_back(s);
+		std::stable_sort(rest.begin(), rest.end(), [&](uint32_t a, uint32_t b) { return must[a] != must[b] ? must[a] > must[b] : w_row[a] > w_row[b]; });
+		for (uint32_t s : rest) {
+			const uint64_t b = H.fresh_base(1, hot_hi);
+			if (!b) {
+				if (must[s]) return fail("the depth-1 rows' targets do not fit the LDS array");
+				base_h[s] = cold_base;
+				n_cold++;
+				continue;
+			}
+			base_h[s] = (uint32_t)b;
+			has_id[s] = 1;
+			if (row_off[s + 1] != row_off[s]) klass[s] = 2; // a partial row that stores nothing
+			else klass[s] = 1;                            // no row at all: every lookup misses, rightly
+		}
+	}
+	// the whole automaton in the global array
 	G.max_base = hot_cap - 1;
+	G.base_cursor = hot_cap;
 	for (uint32_t s = 1; s < S; s++) {
-		if (is_d1[s] || row_off[s + 1] == row_off[s]) continue;
+		if (row_off[s + 1] == row_off[s]) continue;
 		place(G, s, false, hot_cap, 0, &base_g[s]);
 		if (G.max_used + ncodes + 1 > slot_limit) return fail("the automaton needs more slots than the limit");
 	}
+	for (uint32_t s = 1; s < S; s++) // states without a row and without an LDS base: told apart by a global base that stores nothing
+		if (!has_id[s] && (s >= N || reach[s]) && row_off[s + 1] == row_off[s]) base_g[s] = (uint32_t)G.fresh_base(hot_cap, 0);
 	const uint64_t nslots = std::max<uint64_t>(std::max(G.max_used + 1, G.max_base + ncodes + 1), hot_cap); // base + any code is a readable slot
 	if (nslots > slot_limit) return fail("the automaton needs more slots than the limit");
+	// An entry can be in LDS when its target has a base of its own (the others are only ever entered from
+	// the global array, which carries their global base); a row that leaves an entry out is a partial one.
+	auto stored = [&](uint32_t s, uint64_t j) { return (in_lds[s] == 1 || (in_lds[s] == 2 && sel[j] != 0)) && has_id[ent[j].target]; };
+	std::vector<uint8_t> partial_row(S, 0);
+	for (uint32_t s = 1; s < S; s++) {
+		if (row_off[s + 1] == row_off[s]) {
+			partial_row[s] = !has_id[s];
+			continue;
+		}
+		bool all = in_lds[s] == 1;
+		for (uint64_t j = row_off[s]; all && j < row_off[s + 1]; j++) all = stored(s, j);
+		partial_row[s] = !all;
+	}
 	// ---- the image ----
 	out->ncodes = ncodes;
 	out->stride = stride;
 	out->nslots = (uint32_t)nslots;
 	out->hot_slots = hot_cap;
-	out->label_bits = can_split ? 7u : 8u;
-	out->inc_bit = can_split ? 1u << 31 : 0u;
+	out->cold_base = cold_base;
+	out->n_entries = (uint32_t)ent.size();
 	out->hot.assign(hot_cap, DfaImage::kEmptyWord);
-	out->slot.assign(nslots, DfaImage::kEmptyWord);
-	out->crow.assign(hot_cap, 0);
+	out->slot.assign(2 * nslots, 0);
+	for (uint64_t i = 0; i < nslots; i++) out->slot[2 * i] = DfaImage::kEmptyWord;
+	out->gof.assign(hot_cap, 0);
 	out->ev_miss.assign(nslots, DfaImage::kEvNone);
 	out->ev_arr.assign(nslots, DfaImage::kEvNone);
+	out->ent_of.assign(nslots - hot_cap, DfaImage::kEvNone);
 	out->real_slots = out->virtual_slots = out->hot_used = 0;
-	// the word of a state: where its next byte is looked up -- its LDS row if it has one
-	auto state_word = [&](uint32_t s) -> uint32_t {
-		if (is_d1[s]) return base_h[s];
-		if (row_off[s + 1] == row_off[s]) return empty_base;
-		if (klass[s] == 1) return base_h[s];
-		if (klass[s] == 2) return base_h[s] | out->inc_bit;
-		return base_g[s];
-	};
+	// the word of a state: where its next byte is looked up
+	auto state_word = [&](uint32_t s) -> uint32_t { return base_h[s] | (partial_row[s] ? DfaImage::kPartial : 0u); };
+	for (uint32_t s = 1; s < S; s++) { // the states' keys
+		if (s < N && !reach[s]) continue;
+		if (has_id[s]) {
+			out->ev_miss[base_h[s]] = M[s];
+			out->gof[base_h[s]] = partial_row[s] ? base_g[s] : 0u;
+		} else out->ev_miss[base_g[s]] = M[s];
+	}
 	for (uint32_t c = 0; c < ncodes; c++) {
 		out->hot[c] = c << DfaImage::kLabelShift | state_word(d1[c]);
-		out->ev_miss[c] = M[d1[c]];
 		out->real_slots++;
 		out->hot_used++;
 	}
@@ -475,90 +581,92 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	uint32_t n_partial = 0;
 	for (uint32_t s = 1; s < S; s++) {
 		if (row_off[s + 1] == row_off[s]) continue;
-		if (!is_d1[s]) {
-			if (klass[s] == 0) cold_steps += sampled ? w_row[s] : 0;
-			else if (klass[s] == 2) cold_steps += w_miss[s], n_partial++, out->crow[base_h[s]] = base_g[s];
+		if (!is_d1[s] && partial_row[s]) {
+			n_partial++;
+			uint64_t in_lds = 0;
+			for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++)
+				if (stored(s, j)) in_lds += w_ent[j];
+			cold_steps += weighted && w_row[s] > in_lds ? w_row[s] - in_lds : 0;
 		}
 		for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) {
 			const Entry &e = ent[j];
 			const uint32_t word = (uint32_t)e.code << DfaImage::kLabelShift | (e.virt ? DfaImage::kArr : 0u) | state_word(e.target);
-			if (klass[s] == 1 || (klass[s] == 2 && w_ent[j] != 0)) {
+			if (stored(s, j)) {
 				const uint32_t t = base_h[s] + e.code;
 				out->hot[t] = word;
-				out->ev_miss[t] = M[e.target];
 				out->ev_arr[t] = e.arr;
 				out->hot_used++;
 			}
-			if (!is_d1[s]) {
+			{
 				const uint32_t t = base_g[s] + e.code;
-				out->slot[t] = word;
-				out->ev_miss[t] = M[e.target];
+				out->slot[2 * (uint64_t)t] = word;
+				out->slot[2 * (uint64_t)t + 1] = base_g[e.target];
 				out->ev_arr[t] = e.arr;
+				out->ent_of[t - hot_cap] = (uint32_t)j;
 			}
 			if (e.virt) out->virtual_slots++;
 			else out->real_slots++;
 		}
 	}
-	out->sample_cold = sampled ? cold_steps : 0;
+	out->sample_cold = sampled && !(opt.prior && opt.prior_entries == ent.size()) ? cold_steps : 0;
 	out->max_events = max_events;
 	out->valid = true;
 	if (getenv("TOKSCORE_TRACE_HOST"))
-		fprintf(stderr, "BuildDfa: %u slots (%u real, %u virtual entries), LDS array %u of %u used (%zu rows visited, %u chosen, %u found no place, %u partial), "
-		        "%u codes, stride %u; sample: %.4f virtual, %.4f miss, %.6f of the lookups beyond LDS\n",
-		        out->nslots, out->real_slots, out->virtual_slots, out->hot_used, out->hot_slots, order.size(), n_sel, n_demoted, n_partial, ncodes, stride,
+		fprintf(stderr, "BuildDfa: %u slots (%u real, %u virtual entries), LDS array %u of %u used (%zu rows in use, %u chosen, %u found no place, %u partial, "
+		        "%u states without a base of their own), %u codes, stride %u; sample: %.4f virtual, %.4f miss; %.6f of the weighted lookups beyond LDS%s\n",
+		        out->nslots, out->real_slots, out->virtual_slots, out->hot_used, out->hot_slots, order.size(), n_sel, n_demoted, n_partial, n_cold, ncodes, stride,
 		        (double)out->sample_virtual / std::max<uint64_t>(1, out->sample_steps),
-		        (double)out->sample_miss / std::max<uint64_t>(1, out->sample_steps), (double)out->sample_cold / std::max<uint64_t>(1, out->sample_steps));
+		        (double)out->sample_miss / std::max<uint64_t>(1, out->sample_steps),
+		        (double)cold_steps / (double)std::max<uint64_t>(1, std::accumulate(w_row.begin(), w_row.end(), (uint64_t)0)),
+		        opt.prior ? " (with an earlier image's counts)" : "");
 	return true;
 }
 
 void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t V, uint64_t *counts,
-            uint64_t *total_tokens, uint64_t *global_reads) {
+            uint64_t *total_tokens, uint64_t *global_reads, std::vector<uint32_t> *global_hits) {
 	uint64_t n_global = 0;
+	if (global_hits) global_hits->assign(img.nslots - img.hot_slots, 0);
 	for (uint64_t i = 0; i < V + 3; i++) counts[i] = 0;
 	*total_tokens = 0;
 	std::vector<uint64_t> n_miss(img.ev_miss.size(), 0), n_arr(img.ev_arr.size(), 0);
-	uint32_t S = img.start_word(), U = 0;
-	const uint32_t lmask = (1u << img.label_bits) - 1;
-	auto label = [&](uint32_t x) { return (x >> DfaImage::kLabelShift) & lmask; };
+	uint32_t S = img.start_word(), G = 0;
+	uint64_t kind[4] = {0, 0, 0, 0}, steps = 0; // (trace) second looks: partial row miss / hit, no LDS base miss / hit
+	auto label = [&](uint32_t x) { return (x >> DfaImage::kLabelShift) & DfaImage::kLabelMask; };
 	for (uint64_t d = 0; d < D; d++) {
 		for (uint64_t p = off[d]; p <= off[d + 1]; p++) {
 			const uint32_t c = p < off[d + 1] ? img.code[ascii_lower(bytes[p])] : 0u;
-			const uint32_t b = S & DfaImage::kBaseMask, t = b + c;
-			uint32_t x, id = t;
-			bool hit;
-			if (t < img.hot_slots) {
-				x = img.hot[t];
-				hit = label(x) == c;
-				if (!hit && (S & img.inc_bit)) { // a partial row: the row's complete copy decides
-					n_global += 2;
-					id = img.crow[b] + c;
-					x = img.slot[id];
-					hit = label(x) == c;
-				}
-			} else {
+			steps++;
+			const uint32_t b = S & DfaImage::kBaseMask;
+			uint32_t id = b + c; // (always inside the LDS array)
+			uint32_t x = img.hot[id], g_next = G;
+			bool hit = label(x) == c;
+			if (!hit && (S & DfaImage::kPartial)) { // LDS does not hold this state's row completely: its copy in the global array decides
 				n_global++;
-				x = img.slot[t];
+				id = (b == img.cold_base ? G : img.gof[b]) + c;
+				x = img.slot[2 * (uint64_t)id];
 				hit = label(x) == c;
+				if (hit) g_next = img.slot[2 * (uint64_t)id + 1];
+				if (hit && global_hits) (*global_hits)[id - img.hot_slots]++;
+				kind[(b == img.cold_base ? 2 : 0) + (hit ? 1 : 0)]++;
 			}
 			if (hit) {
 				if (x & DfaImage::kArr) n_arr[id]++;
 				S = x;
-				U = id;
+				G = g_next;
 			} else {
-				n_miss[U]++;
+				n_miss[b == img.cold_base ? G : b]++;
 				S = c * img.stride;
-				U = c;
 			}
 		}
 	}
 	// (the run ends in the separator's state: nothing is pending)
 	std::vector<uint32_t> ids;
 	for (size_t t = 0; t < n_miss.size(); t++) {
-		for (int kind = 0; kind < 2; kind++) {
-			const uint64_t n = kind ? n_arr[t] : n_miss[t];
+		for (int k = 0; k < 2; k++) {
+			const uint64_t n = k ? n_arr[t] : n_miss[t];
 			if (!n) continue;
 			ids.clear();
-			img.event_ids(kind ? img.ev_arr[t] : img.ev_miss[t], &ids);
+			img.event_ids(k ? img.ev_arr[t] : img.ev_miss[t], &ids);
 			for (uint32_t id : ids) {
 				counts[id] += n;
 				*total_tokens += n;
@@ -567,6 +675,9 @@ void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint
 	}
 	counts[0] = counts[1] = D; // START / END once per document (SolutionFile.cpp:85,98)
 	if (global_reads) *global_reads = n_global;
+	if (getenv("TOKSCORE_TRACE_HOST"))
+		fprintf(stderr, "DfaRun: %llu steps; second looks: partial row %llu miss %llu hit, no base of its own %llu miss %llu hit\n", (unsigned long long)steps,
+		        (unsigned long long)kind[0], (unsigned long long)kind[1], (unsigned long long)kind[2], (unsigned long long)kind[3]);
 }
 
 } // namespace tokscore

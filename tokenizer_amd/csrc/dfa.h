@@ -23,8 +23,8 @@
 // Token counts come from events, not from ids: the kernel logs the slot whose state it left by a miss
 // (ev_miss[slot] = every token of the chain) and the virtual slot it arrived on (ev_arr[slot]); the
 // histogram over slots is turned into counts[id] with these tables at the end of an evaluation.
-// What LDS holds is chosen entry by entry (a 2 MB sample of the corpus run through the automaton says
-// which entries are used): see DfaImage below.
+// What LDS holds is chosen entry by entry (a sample of the corpus run through the automaton, and after
+// a plan's first evaluation the scan's own counters, say which entries are used): see DfaImage below.
 #pragma once
 
 #include <cstdint>
@@ -34,37 +34,48 @@
 namespace tokscore {
 
 struct DfaImage {
-	// slot word: partial : 1 | label (code) : 7 | kArr : 1 | base : 23 -- or, with more than 127 codes,
-	// label : 8 | kArr : 1 | base : 23 and no partial rows (label_bits, inc_bit).  The state a slot
-	// stands for looks its next byte up at slot base + code; `partial` says that state's LDS row is a
-	// partial one.  Empty slots carry the all-ones label, which no code equals.
-	static constexpr uint32_t kLabelShift = 24;
-	static constexpr uint32_t kArr = 0x800000u;
-	static constexpr uint32_t kBaseMask = 0x7FFFFFu;
-	static constexpr uint32_t kEmptyWord = 0xFF000000u;
-	static constexpr uint32_t kMaxCodes = 254;      // codes 0 .. ncodes - 1 < 255
+	// slot word: kArr : 1 | 0 : 7 | partial : 1 | label (code) : 7 | base : 16.  The state a word stands
+	// for looks its next byte up at slot base + code OF THE LDS ARRAY; `partial` says that LDS does not
+	// hold that state's row completely, so a miss there proves nothing.  Empty slots carry the all-ones
+	// label, which no code equals.  Bits 24 - 30 are zero in every word (the scan's loop marks lanes there:
+	// one compare of the top byte then finds both the marked lanes and the arrivals on kArr entries).
+	static constexpr uint32_t kLabelShift = 16;
+	static constexpr uint32_t kLabelMask = 0x7Fu;
+	static constexpr uint32_t kArr = 0x80000000u;
+	static constexpr uint32_t kPartial = 0x800000u;
+	static constexpr uint32_t kBaseMask = 0xFFFFu;
+	static constexpr uint32_t kEmptyWord = 0x7F0000u;
+	static constexpr uint32_t kMaxCodes = 127;      // codes 0 .. ncodes - 1 in the label's 7 bits, all ones = empty
+	static constexpr uint32_t kMaxHot = 65536;      // (the base's 16 bits)
 	static constexpr uint64_t kMaxSlots = 1u << 23;
 	// events: kEvNone = nothing to count, id < 2^31 = one token id, kEvList | o = pool[o] ids at pool[o + 1 ..]
 	static constexpr uint32_t kEvNone = 0xFFFFFFFFu;
 	static constexpr uint32_t kEvList = 0x80000000u;
 
 	// Two arrays over one index space.  `slot` [hot_slots, nslots) holds the whole automaton, read from
-	// global memory (L2): every state's row, complete.  `hot` [0, hot_slots) is what the scan keeps in
-	// LDS: the root row, the depth-1 rows, and an overlay for the rows the sample visited -- a row is
-	// there COMPLETE, or PARTIAL: only the entries the sample used; a miss in a partial row (inc_bit
-	// set in its state's word) is looked up again at crow[base] + code, the row's complete copy.  A
-	// state's word names its LDS row when it has one, so a walk that left LDS is back at the next
-	// entry that leads to a visited state.  An entry's event index is the index of the slot it was
-	// read from (either array).
+	// global memory (L2): every state's row, complete, at the state's GLOBAL base.  `hot` [0, hot_slots)
+	// is what the scan keeps in LDS: the root row, the depth-1 rows, and an overlay for the rows that are
+	// used -- a row is there COMPLETE, or PARTIAL: only the entries in use.
+	//   A state is known by its LDS base, a value no other state has (a state without a row, or whose row
+	// LDS does not hold at all, still gets a base of its own while values last: a base needs no slots,
+	// only that no other row starts there, so every lookup at base + code misses).  States beyond that
+	// share `cold_base` and are told apart by their global base, which the scan carries beside the state
+	// word while it is in one of them; they are only ever entered from the global array, whose entries
+	// hold the target's global base in a second word.  A word's `partial` bit is set for partial rows and
+	// for cold_base: after a miss in LDS the lookup is repeated at global base + code, the global base
+	// being gof[LDS base], or the carried one under cold_base.
+	//   Events are counted per key: leaving a state by a miss under the state's key (its LDS base, or its
+	// global base under cold_base), arriving on a virtual entry under the entry's index (either array).
 	std::vector<uint32_t> hot;
-	std::vector<uint32_t> slot;
-	std::vector<uint32_t> crow;    // [hot_slots] by LDS base: base of the same state's row in `slot` (partial rows)
-	std::vector<uint32_t> ev_miss; // [nslots] by event index: what leaving the entry's state by a miss emits
-	std::vector<uint32_t> ev_arr;  // ... what arriving on it emits (kArr entries only)
+	std::vector<uint32_t> slot;    // [2 * nslots]: slot[2 i] the word of entry i, slot[2 i + 1] its target's global base (i >= hot_slots)
+	std::vector<uint32_t> gof;     // [hot_slots] by LDS base: the state's global base (0: its row is complete in LDS, or it has none)
+	std::vector<uint32_t> ev_miss; // [nslots] by state key: what leaving the state by a miss emits
+	std::vector<uint32_t> ev_arr;  // [nslots] by entry index: what arriving on a virtual entry emits
+	std::vector<uint32_t> ent_of;  // [nslots - hot_slots] host only: global entry -> the builder's entry number (kEvNone: none)
 	uint32_t hot_slots = 0;        // = DfaOptions::lds_slots
-	uint32_t label_bits = 8;       // 7 when the partial bit exists
-	uint32_t inc_bit = 0;          // 1 << 31 then (the word's sign: one compare in the kernel)
+	uint32_t cold_base = 0;
 	uint32_t hot_used = 0;         // entries in `hot`
+	uint32_t n_entries = 0;        // the builder's entries (DfaOptions::prior's length)
 	uint64_t sample_cold = 0;      // sample lookups that needed `slot`
 	std::vector<uint32_t> pool;
 	uint8_t code[256] = {};
@@ -78,7 +89,7 @@ struct DfaImage {
 	bool valid = false;
 
 	// the state after a document separator: slot 0 (the root row is the separator's row)
-	uint32_t start_word() const { return hot.empty() ? 0u : hot[0]; }
+	uint32_t start_word() const { return hot.empty() ? 0u : hot[0] & (kBaseMask | kPartial); }
 	// share of the sample's lookups that `hot` alone answered
 	double hot_fraction() const;
 	// appends an event's ids to out (with repetitions)
@@ -88,15 +99,22 @@ struct DfaImage {
 struct DfaOptions {
 	uint32_t lds_slots = 40000;    // slots of the LDS array
 	uint64_t max_slots = 6u << 20; // give up above this many slots (virtual slots of deep vocabularies run into tens of millions)
-	const uint8_t *sample = nullptr; // raw corpus bytes for the hot-first order (lower-cased here)
+	const uint8_t *sample = nullptr; // raw corpus bytes for the choice of what LDS holds (lower-cased here)
 	uint64_t sample_bytes = 0;
+	uint64_t corpus_bytes = 0;     // what the sample stands for (scales its counts against `prior`)
+	// uses of the builder's entries an earlier image of the SAME vocabulary counted on the whole corpus
+	// (the scan's counters of the global array, through DfaImage::ent_of), or null
+	const uint32_t *prior = nullptr;
+	uint32_t prior_entries = 0;
 };
 
 // Host-side check of an image (CPU tests of the builder; never used by a scoring entry point): runs
 // the automaton over documents exactly as the kernel does -- codes of the lower-cased bytes, a
 // separator after every document -- and adds up counts[V + 3] and total_tokens from the events.
-// *global_reads (optional): reads of the global array the run made (a partial row's second look counts two).
+// *global_reads (optional): lookups the run repeated in the global array.
+// *global_hits (optional): per entry of the global array (index - hot_slots), the hits of those lookups --
+// what the scan's counters hold after an evaluation.
 void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t V, uint64_t *counts,
-            uint64_t *total_tokens, uint64_t *global_reads = nullptr);
+            uint64_t *total_tokens, uint64_t *global_reads = nullptr, std::vector<uint32_t> *global_hits = nullptr);
 
 } // namespace tokscore

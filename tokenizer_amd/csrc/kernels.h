@@ -225,16 +225,15 @@ void launch_histogram_events(const StreamDev &Q, uint32_t nslots, const uint32_t
 
 // kernels_dfa.hip -- full evaluation on the one-transition-per-byte automaton (dfa.h)
 struct DfaDev {
-	const uint32_t *hot;     // [hot_slots, padded to 16 bytes] the LDS array: label : 8 | kArr : 1 | base : 23
-	const uint32_t *slot;    // [nslots] the global array: the whole automaton, rows at bases >= hot_slots
-	const uint32_t *crow;    // [hot_slots] by LDS base: base of a partial row's complete copy in `slot`
-	const uint32_t *ev_miss; // [nslots] by event index (= slot index in either array): leaving the entry's state by a miss
-	const uint32_t *ev_arr;  // ... arriving on a virtual entry
+	const uint32_t *hot;     // [hot_slots, padded to 16 bytes] the LDS array (dfa.h: kArr | 0 : 7 | partial | label : 7 | base : 16)
+	const uint2 *slot;       // [nslots] the global array: .x the entry's word, .y its target's global base; rows at bases >= hot_slots
+	const uint32_t *gof;     // [hot_slots] by LDS base: the state's global base
+	const uint32_t *ev_miss; // [nslots] by state key (LDS base, or global base under cold_base): leaving the state by a miss
+	const uint32_t *ev_arr;  // [nslots] by entry index (either array): arriving on a virtual entry
 	const uint32_t *pool;    // event lists
 	uint32_t nslots;
-	uint32_t hot_slots;      // events with an index below it go to the streams, the others to counters
-	uint32_t label_bits;     // 7: partial : 1 | label : 7 | kArr | base : 23; 8: label : 8 | kArr | base : 23
-	uint32_t inc_bit;        // the partial bit (0: none): a miss in `hot` from such a state is looked up at crow[base] + code
+	uint32_t hot_slots;      // keys and entries below it go to the streams, the others to counters
+	uint32_t cold_base;      // the LDS base of the states without one of their own
 	uint32_t stride;         // the depth-1 state of code c has its row at c * stride
 };
 struct DfaWork {
@@ -242,12 +241,13 @@ struct DfaWork {
 	uint32_t range_bytes;    // multiple of 8
 	uint32_t nranges;        // nwb * 64 * chains
 	uint32_t nwb;            // wave blocks: 64 lanes x `chains` ranges each
-	uint2 *entry;            // [nranges] state (base | kArr, event slot) the range's count starts from
+	uint2 *entry;            // [nranges] state (word, global base) the range's count starts from
 	uint2 *exit_a;           // [nranges] state the scan ended the range in
 	uint2 *exit_b;           // [nranges] ... after the fix-up, where exit_tag[g] == the evaluation's epoch
 	uint32_t *exit_tag;
-	uint32_t *cold_miss;     // [nslots] events with index hot_slots + i (zero between evaluations)
+	uint32_t *cold_miss;     // [nslots - hot_slots] by key / entry hot_slots + i (zero between evaluations)
 	uint32_t *cold_arr;
+	uint32_t *cold_hit;      // ... hits in the global array, by entry (never cleared by an evaluation: the host reads it for the next layout)
 };
 struct DfaScanPlan {
 	uint32_t blocks, waves_per_block, chains;
@@ -267,10 +267,14 @@ void launch_dfa_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_
                         const StreamDev &Qa, uint32_t first_batches, uint32_t *changed, hipStream_t stream);
 void launch_dfa_scan(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, const StreamDev &Qa, const DfaScanPlan &plan,
                      hipStream_t stream, const OutInit &init = OutInit{}, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-// codes: the prepared corpus (linear), readable up to nranges * range_bytes; changed: two words, zero on entry
-void launch_dfa_fixup(const DfaDev &A, const DfaWork &W, const uint8_t *codes, uint32_t *changed, uint32_t epoch,
-                      unsigned long long *out, uint32_t total_index, hipStream_t stream);
-void launch_dfa_cold_reduce(const DfaDev &A, const DfaWork &W, unsigned long long *out, uint32_t total_index, hipStream_t stream);
+// After the scan, two launches: the fix-up of the range entries and the histograms of both streams (miss_blocks +
+// arrival_blocks workgroups, a slab row of 16 bits x hot_slots each), then the slab's column sums and the
+// global array's counters through the event tables into out; the cursors go back to first_batches and
+// changed[0..1] to zero for the next evaluation.  codes: the prepared corpus (linear), readable up to
+// nranges * range_bytes.
+void launch_dfa_count(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, const StreamDev &Qa, const uint8_t *codes,
+                      uint32_t *changed, uint32_t epoch, unsigned long long *out, uint32_t total_index, uint32_t *slab,
+                      uint32_t miss_blocks, uint32_t arrival_blocks, uint32_t first_batches, hipStream_t stream);
 
 // kernels_count.hip -- closed-vocabulary all-occurrence counting (GetTokens.cpp:21-27)
 struct CountPlan {

@@ -37,8 +37,40 @@ namespace tokscore {
 namespace {
 
 constexpr uint32_t kDfaBatchEntries = kStreamBatch * 512; // u16 entries of one stream batch (32 KiB)
-constexpr uint32_t kArr = 0x800000u, kBaseMask = 0x7FFFFFu;
+constexpr uint32_t kArr = 0x80000000u, kPartial = 0x800000u, kBaseMask = 0xFFFFu, kLabelMask = 0x7Fu, kLabelShift = 16; // (dfa.h: DfaImage)
 constexpr uint32_t kEvNone = 0xFFFFFFFFu, kEvList = 0x80000000u;
+
+// One transition, as every path here takes it (the scan's loop in assembly does the same: tools/gen_dfa_asm.py).
+// S: state word, G: the state's global base while S is under cold_base.  Returns true for a hit; *id = the
+// entry arrived on (either array), *key = the key of the state left (what a miss counts under).
+struct DfaStep {
+	uint32_t x, id, g_next;
+	bool hit, second_look;
+};
+template <typename HotArray>
+__device__ __forceinline__ DfaStep dfa_step(const DfaDev &A, HotArray hot, uint32_t S, uint32_t G, uint32_t c) {
+	DfaStep r;
+	const uint32_t b = S & kBaseMask;
+	r.id = b + c; // (always inside the LDS array)
+	r.x = hot[r.id];
+	r.g_next = G;
+	r.hit = ((r.x >> kLabelShift) & kLabelMask) == c;
+	r.second_look = !r.hit && (S & kPartial) != 0;
+	return r;
+}
+// LDS does not hold the state's row completely: its copy in the global array decides
+__device__ __forceinline__ void dfa_second_look(const DfaDev &A, DfaStep &r, uint32_t S, uint32_t G, uint32_t c) {
+	const uint32_t b = S & kBaseMask;
+	r.id = (b == A.cold_base ? G : A.gof[b]) + c;
+	const uint2 w = A.slot[r.id];
+	r.x = w.x;
+	r.hit = ((r.x >> kLabelShift) & kLabelMask) == c;
+	if (r.hit) r.g_next = w.y;
+}
+__device__ __forceinline__ uint32_t dfa_key(const DfaDev &A, uint32_t S, uint32_t G) {
+	const uint32_t b = S & kBaseMask;
+	return b == A.cold_base ? G : b;
+}
 
 // The ranges transposed: 8-byte piece p of chain j of lane l of wave block wb at
 // ((wb * pieces + p) * C + j) * 64 + l (in pieces); range g = (wb * C + j) * 64 + l.
@@ -67,7 +99,7 @@ __global__ void __launch_bounds__(256) dfa_transpose_kernel(const uint8_t *prep,
 // entry states of a new plan: the separator's state everywhere; cursors and fix-up words
 __global__ void __launch_bounds__(256) dfa_reset_states_kernel(uint2 *entry, uint32_t nranges, uint32_t start_word) {
 	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nranges; g += gridDim.x * blockDim.x)
-		entry[g] = uint2{start_word & kBaseMask, 0u};
+		entry[g] = uint2{start_word & (kBaseMask | kPartial), 0u};
 }
 
 __global__ void __launch_bounds__(256) dfa_prepare_kernel(unsigned long long *out, uint32_t V, unsigned long long D,
@@ -141,15 +173,15 @@ __global__ void __launch_bounds__(1024) dfa_scan_kernel(DfaDev A, DfaWork W, Str
 	lm.open_own(Qm, wave_id);
 	la.open_own(Qa, wave_id);
 	const uint32_t pieces = W.range_bytes / 8;
-	const uint32_t hot_slots = A.hot_slots, inc_bit = A.inc_bit, lmask = (1u << A.label_bits) - 1, stride = A.stride;
+	const uint32_t hot_slots = A.hot_slots, stride = A.stride;
 	constexpr uint32_t kHigh = kDfaBatchEntries - 8 * C * 64;
 
 	for (uint32_t wb = wave_id; wb < W.nwb; wb += total_waves) {
-		uint32_t S[C], U[C];
+		uint32_t S[C], G[C];
 #pragma unroll
 		for (int j = 0; j < C; j++) {
 			const uint2 e = W.entry[(wb * C + j) * 64 + lane];
-			S[j] = e.x, U[j] = e.y;
+			S[j] = e.x, G[j] = e.y;
 		}
 		const uint2 *src = W.tcodes + (size_t)wb * pieces * C * 64 + lane;
 		uint2 cur[C], nxt[C];
@@ -166,30 +198,23 @@ __global__ void __launch_bounds__(1024) dfa_scan_kernel(DfaDev A, DfaWork W, Str
 				for (int j = 0; j < C; j++) {
 					const uint32_t w = k < 4 ? cur[j].x : cur[j].y;
 					const uint32_t c = (w >> (8 * (k & 3))) & 0xFFu;
-					const uint32_t b = S[j] & kBaseMask, t = b + c;
-					uint32_t x, id = t;
-					if (t < hot_slots) x = img[t];
-					else x = A.slot[t];
-					bool hit = ((x >> 24) & lmask) == c;
-					// a partial row (dfa.h): a miss proves nothing, the row's complete copy in the global array decides
-					const bool again = !hit && (S[j] & inc_bit) != 0;
-					if (__builtin_amdgcn_ballot_w64(again) != 0) {
-						if (again) {
-							id = A.crow[b] + c;
-							x = A.slot[id];
-							hit = ((x >> 24) & lmask) == c;
+					DfaStep r = dfa_step(A, img, S[j], G[j], c);
+					if (__builtin_amdgcn_ballot_w64(r.second_look) != 0) {
+						if (r.second_look) {
+							dfa_second_look(A, r, S[j], G[j], c);
+							if (r.hit) atomicAdd(&W.cold_hit[r.id - hot_slots], 1u);
 						}
 					}
-					const bool arr = hit && (x & kArr) != 0;
-					// the state left by a miss: its entry's index to the miss stream (or, beyond the LDS array, its counter)
-					lm.put(!hit && U[j] < hot_slots, U[j]);
-					if (!hit && U[j] >= hot_slots) atomicAdd(&W.cold_miss[U[j] - hot_slots], 1u);
+					const bool arr = r.hit && (r.x & kArr) != 0;
+					// the state left by a miss: its base to the miss stream (cold_base counts for nothing: such a state has a counter)
+					lm.put(!r.hit, S[j] & kBaseMask);
+					if (!r.hit && (S[j] & kBaseMask) == A.cold_base) atomicAdd(&W.cold_miss[G[j] - hot_slots], 1u);
 					if (__builtin_amdgcn_ballot_w64(arr) != 0) {
-						la.put(arr && id < hot_slots, id);
-						if (arr && id >= hot_slots) atomicAdd(&W.cold_arr[id - hot_slots], 1u);
+						la.put(arr && r.id < hot_slots, r.id);
+						if (arr && r.id >= hot_slots) atomicAdd(&W.cold_arr[r.id - hot_slots], 1u);
 					}
-					S[j] = hit ? x : c * stride;
-					U[j] = hit ? id : c;
+					S[j] = r.hit ? r.x : c * stride;
+					G[j] = r.g_next;
 				}
 			}
 #pragma unroll
@@ -198,227 +223,19 @@ __global__ void __launch_bounds__(1024) dfa_scan_kernel(DfaDev A, DfaWork W, Str
 			if (la.cur > kHigh) la.roll(Qa, lane);
 		}
 #pragma unroll
-		for (int j = 0; j < C; j++) W.exit_a[(wb * C + j) * 64 + lane] = uint2{S[j] & (kBaseMask | inc_bit), U[j]};
+		for (int j = 0; j < C; j++) W.exit_a[(wb * C + j) * 64 + lane] = uint2{S[j] & (kBaseMask | kPartial), G[j]};
 	}
 	lm.close(Qm, lane);
 	la.close(Qa, lane);
 }
 
 // ---- the scan's loop, hand-written for gfx950 -------------------------------------------------
-// One step of one chain = DFA_ISSUE (where the next slot is: 3 vector instructions and the LDS read)
-// and, after the other chains' steps have covered the read's latency, DFA_RESOLVE (what it says: 11
-// vector, 1 store and 14 scalar instructions on the common path).  The byte never becomes a
-// register of its own: the four instructions that need it select it from the window dword (SDWA).
-// exec is all ones throughout (every lane has a range; ranges are equal).  Per chain: window
-// W0 W1, next piece N0 N1, T slot index, X slot word, L label / LDS address, M the state after a
-// miss.  v20 v21 scratch, v32 stride, v33 0x7f, v34 1; s[38:39] all lanes, s[40:55] scratch:
-//   s[40:41] lanes whose slot lies beyond the LDS array, s[42:43] lanes the global array decides,
-//   s[44:45] miss lanes, s[52:53] lanes whose new event index lies beyond the LDS array.
-// Rare paths, each behind one scalar branch: the global array (lane by lane with scalar loads -- a
-// row beyond LDS: one; a partial row: crow[base], then the slot -- because a vector load's wait would
-// also wait for every store before it), events with an index beyond the LDS array (a counter each
-// instead of the 16-bit stream), arrivals on virtual entries.
-#define DFA_RES_HEAD \
-	".macro DFA_RESOLVE n, w, sel, s, u, t, x, l, m, uc\n"                                              \
-	"  s_waitcnt lgkmcnt(\\n)\n"                                                                        \
-	"  v_bfe_u32 \\l, \\x, 24, %[lbits]\n"
-#define DFA_RES_HIT \
-	"  v_cmp_eq_u32_sdwa vcc, \\w, \\l src0_sel:BYTE_\\sel src1_sel:DWORD\n" /* hit */
-#ifdef DFA_EXP_NOSLOW /* (timing experiment: no lookups beyond LDS; results wrong unless LDS holds everything) */
-#define DFA_RES_SLOWTEST ""
-#define DFA_RES_SLOW "  s_mov_b64 s[52:53], 0\n"
-#else
-#define DFA_RES_SLOWTEST \
-	"  v_cmp_le_u32_e64 s[40:41], %[hot], \\t\n"                                                        \
-	"  v_cmp_gt_i32_e64 s[42:43], 0, \\s\n"             /* the state's LDS row is a partial one */
-#define DFA_RES_SLOW \
-	"  s_andn2_b64 s[42:43], s[42:43], vcc\n"                                                           \
-	"  s_or_b64 s[42:43], s[42:43], s[40:41]\n"                                                         \
-	"  s_mov_b64 s[52:53], 0\n"                                                                         \
-	"  s_cmp_eq_u64 s[42:43], 0\n"                                                                      \
-	"  s_cbranch_scc1 .Lfast%=_\\@\n"                                                                      \
-	"  s_andn2_b64 s[50:51], vcc, s[42:43]\n"           /* ---- the global array decides ---- */        \
-	"  s_mov_b64 s[56:57], s[42:43]\n"                  /* lane by lane, through the scalar cache: a    \
-	                                                       vector load would wait for the stores too */  \
-	".Lwf%=_\\@:\n"                                                                                     \
-	"  s_ff1_i32_b64 s58, s[56:57]\n"                                                                   \
-	"  v_readlane_b32 s59, \\t, s58\n"                  /* slot index (right for a row beyond LDS) */   \
-	"  s_bitcmp1_b64 s[40:41], s58\n"                                                                   \
-	"  s_cbranch_scc1 .Lwc%=_\\@\n"                                                                     \
-	"  v_readlane_b32 s60, \\s, s58\n"                  /* a partial row: crow[base] + code */          \
-	"  v_readlane_b32 s61, \\w, s58\n"                                                                  \
-	"  s_and_b32 s60, s60, 0x7fffff\n"                                                                  \
-	"  s_lshl_b32 s60, s60, 2\n"                                                                        \
-	"  s_load_dword s59, %[crow], s60\n"                                                                \
-	"  s_bfe_u32 s61, s61, (\\sel * 8) | 0x80000\n"                                                     \
-	"  s_waitcnt lgkmcnt(0)\n"                                                                          \
-	"  s_add_u32 s59, s59, s61\n"                                                                       \
-	".Lwc%=_\\@:\n"                                                                                     \
-	"  s_lshl_b32 s60, s59, 2\n"                                                                        \
-	"  s_load_dword s60, %[slot], s60\n"                                                                \
-	"  s_bitset0_b64 s[56:57], s58\n"                                                                   \
-	"  s_mov_b32 m0, s58\n"                            /* (writelane takes one SGPR: the lane comes from m0) */ \
-	"  s_waitcnt lgkmcnt(0)\n"                                                                          \
-	"  v_writelane_b32 \\x, s60, m0\n"                                                                  \
-	"  v_writelane_b32 \\t, s59, m0\n"                                                                 \
-	"  s_cmp_lg_u64 s[56:57], 0\n"                                                                      \
-	"  s_cbranch_scc1 .Lwf%=_\\@\n"                                                                     \
-	"  s_mov_b64 exec, s[42:43]\n"                                                                      \
-	"  v_bfe_u32 \\l, \\x, 24, %[lbits]\n"                                                              \
-	"  v_cmp_eq_u32_sdwa vcc, \\w, \\l src0_sel:BYTE_\\sel src1_sel:DWORD\n"                            \
-	"  s_mov_b64 s[52:53], vcc\n"                       /* their new event index is a global one */     \
-	"  s_or_b64 vcc, vcc, s[50:51]\n"                                                                   \
-	"  s_mov_b64 exec, s[38:39]\n"                                                                      \
-	".Lfast%=_\\@:\n"
-#endif
-#ifdef DFA_EXP_NOLOG /* (timing experiment: no miss events; results wrong) */
-#define DFA_RES_LOG ""
-#else
-#define DFA_RES_LOG \
-	"  s_andn2_b64 s[44:45], s[38:39], vcc\n"           /* ---- the states left by a miss ---- */       \
-	"  s_and_b64 s[46:47], s[44:45], \\uc\n"                                                            \
-	"  s_cbranch_scc0 .Lnocu%=_\\@\n"                                                                      \
-	"  s_mov_b64 exec, s[46:47]\n"                      /* event index beyond LDS: its counter */       \
-	"  v_subrev_u32 v21, %[hot], \\u\n"                                                                 \
-	"  v_lshlrev_b32 v21, 2, v21\n"                                                                     \
-	"  global_atomic_add v21, v34, %[cmiss]\n"                                                          \
-	".Lnocu%=_\\@:\n"                                                                                      \
-	"  s_andn2_b64 exec, s[44:45], \\uc\n"                                                              \
-	"  s_bcnt1_i32_b64 s48, exec\n"                                                                     \
-	"  s_cmp_eq_u32 s48, 0\n"                          /* no lane: lane 0 stores an entry nobody counts, */ \
-	"  s_cselect_b64 exec, 1, exec\n"                  /* so that every step issues one store (vmcnt)   */ \
-	"  v_mbcnt_lo_u32_b32 v20, exec_lo, 0\n"                                                            \
-	"  v_mbcnt_hi_u32_b32 v20, exec_hi, v20\n"          /* rank among them */                           \
-	"  v_lshl_add_u32 v20, v20, 1, %[curm]\n"                                                           \
-	"  global_store_short v20, \\u, %[basem]\n"                                                         \
-	"  s_lshl1_add_u32 %[curm], s48, %[curm]\n"                                                         \
-	"  s_mov_b64 exec, s[38:39]\n"
-#endif
-#ifdef DFA_EXP_NOARR /* (timing experiment: no arrival events; results wrong) */
-#define DFA_RES_ARR ""
-#else
-#define DFA_RES_ARR \
-	"  v_cmp_lt_u32_sdwa s[46:47], v33, \\x src0_sel:DWORD src1_sel:BYTE_2\n" /* kArr */                \
-	"  s_and_b64 s[46:47], s[46:47], vcc\n"             /* ---- arrivals on virtual entries ---- */     \
-	"  s_cbranch_scc0 .Lnoarr%=_\\@\n"                                                                     \
-	"  s_andn2_b64 exec, s[46:47], s[52:53]\n"                                                          \
-	"  v_mbcnt_lo_u32_b32 v20, exec_lo, 0\n"                                                            \
-	"  v_mbcnt_hi_u32_b32 v20, exec_hi, v20\n"                                                          \
-	"  v_lshl_add_u32 v20, v20, 1, %[cura]\n"                                                           \
-	"  global_store_short v20, \\t, %[basea]\n"                                                         \
-	"  s_bcnt1_i32_b64 s48, exec\n"                                                                     \
-	"  s_lshl1_add_u32 %[cura], s48, %[cura]\n"                                                         \
-	"  s_and_b64 exec, s[46:47], s[52:53]\n"                                                            \
-	"  s_cbranch_execz .Larrdone%=_\\@\n"                                                                  \
-	"  v_subrev_u32 v21, %[hot], \\t\n"                                                                 \
-	"  v_lshlrev_b32 v21, 2, v21\n"                                                                     \
-	"  global_atomic_add v21, v34, %[carr]\n"                                                           \
-	".Larrdone%=_\\@:\n"                                                                                   \
-	"  s_mov_b64 exec, s[38:39]\n"                                                                      \
-	".Lnoarr%=_\\@:\n"
-#endif
-#define DFA_RES_TAIL \
-	"  v_mul_u32_u24_sdwa \\m, \\w, v32 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_\\sel src1_sel:DWORD\n" \
-	"  v_cndmask_b32_e32 \\s, \\m, \\x, vcc\n"          /* the next state */                            \
-	"  v_cndmask_b32_sdwa \\u, \\w, \\t, vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_\\sel src1_sel:DWORD\n" \
-	"  s_mov_b64 \\uc, s[52:53]\n"                                                                      \
-	".endm\n"
-#define DFA_ASM_MACROS                                                                                  \
-	".macro DFA_ISSUE w, sel, s, t, a, x\n"                                                             \
-	"  v_and_b32 \\t, 0x7fffff, \\s\n"                                                                  \
-	"  v_add_u32_sdwa \\t, \\w, \\t dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_\\sel src1_sel:DWORD\n" \
-	"  v_lshlrev_b32 \\a, 2, \\t\n"                                                                     \
-	"  ds_read_b32 \\x, \\a\n"                                                                          \
-	".endm\n"                                                                                           \
-	DFA_RES_HEAD DFA_RES_SLOWTEST DFA_RES_HIT DFA_RES_SLOW DFA_RES_LOG DFA_RES_ARR DFA_RES_TAIL
-// chain j: W0 W1 N0 N1 T X L M = v[40 + 8 j ...]
-#define DFA_I0(w, sel) "DFA_ISSUE " w ", " #sel ", %[S0], v44, v46, v45\n"
-#define DFA_I1(w, sel) "DFA_ISSUE " w ", " #sel ", %[S1], v52, v54, v53\n"
-#define DFA_I2(w, sel) "DFA_ISSUE " w ", " #sel ", %[S2], v60, v62, v61\n"
-#define DFA_I3(w, sel) "DFA_ISSUE " w ", " #sel ", %[S3], v68, v70, v69\n"
-#define DFA_R0(n, w, sel) "DFA_RESOLVE " #n ", " w ", " #sel ", %[S0], %[U0], v44, v45, v46, v47, %[UC0]\n"
-#define DFA_R1(n, w, sel) "DFA_RESOLVE " #n ", " w ", " #sel ", %[S1], %[U1], v52, v53, v54, v55, %[UC1]\n"
-#define DFA_R2(n, w, sel) "DFA_RESOLVE " #n ", " w ", " #sel ", %[S2], %[U2], v60, v61, v62, v63, %[UC2]\n"
-#define DFA_R3(n, w, sel) "DFA_RESOLVE " #n ", " w ", " #sel ", %[S3], %[U3], v68, v69, v70, v71, %[UC3]\n"
-// one byte of every chain resolved and the next one issued (a*: the window dwords of this byte, b*: of the next)
-#define DFA_K1(a0, sel, b0, seln) DFA_R0(0, a0, sel) DFA_I0(b0, seln)
-#define DFA_K2(a0, a1, sel, b0, b1, seln) DFA_R0(1, a0, sel) DFA_I0(b0, seln) DFA_R1(1, a1, sel) DFA_I1(b1, seln)
-#define DFA_K4(a0, a1, a2, a3, sel, b0, b1, b2, b3, seln)                                               \
-	DFA_R0(3, a0, sel) DFA_I0(b0, seln) DFA_R1(3, a1, sel) DFA_I1(b1, seln) DFA_R2(3, a2, sel) DFA_I2(b2, seln)   \
-	DFA_R3(3, a3, sel) DFA_I3(b3, seln)
-#define DFA_BODY1                                                                                       \
-	DFA_I0("v40", 0) DFA_K1("v40", 0, "v40", 1) DFA_K1("v40", 1, "v40", 2) DFA_K1("v40", 2, "v40", 3)           \
-	DFA_K1("v40", 3, "v41", 0) DFA_K1("v41", 0, "v41", 1) DFA_K1("v41", 1, "v41", 2) DFA_K1("v41", 2, "v41", 3) \
-	DFA_R0(0, "v41", 3)
-#define DFA_BODY2                                                                                       \
-	DFA_I0("v40", 0) DFA_I1("v48", 0)                                                                   \
-	DFA_K2("v40", "v48", 0, "v40", "v48", 1) DFA_K2("v40", "v48", 1, "v40", "v48", 2)                       \
-	DFA_K2("v40", "v48", 2, "v40", "v48", 3) DFA_K2("v40", "v48", 3, "v41", "v49", 0)                       \
-	DFA_K2("v41", "v49", 0, "v41", "v49", 1) DFA_K2("v41", "v49", 1, "v41", "v49", 2)                       \
-	DFA_K2("v41", "v49", 2, "v41", "v49", 3) DFA_R0(1, "v41", 3) DFA_R1(0, "v49", 3)
-#define DFA_BODY4                                                                                       \
-	DFA_I0("v40", 0) DFA_I1("v48", 0) DFA_I2("v56", 0) DFA_I3("v64", 0)                                 \
-	DFA_K4("v40", "v48", "v56", "v64", 0, "v40", "v48", "v56", "v64", 1)                                \
-	DFA_K4("v40", "v48", "v56", "v64", 1, "v40", "v48", "v56", "v64", 2)                                \
-	DFA_K4("v40", "v48", "v56", "v64", 2, "v40", "v48", "v56", "v64", 3)                                \
-	DFA_K4("v40", "v48", "v56", "v64", 3, "v41", "v49", "v57", "v65", 0)                                \
-	DFA_K4("v41", "v49", "v57", "v65", 0, "v41", "v49", "v57", "v65", 1)                                \
-	DFA_K4("v41", "v49", "v57", "v65", 1, "v41", "v49", "v57", "v65", 2)                                \
-	DFA_K4("v41", "v49", "v57", "v65", 2, "v41", "v49", "v57", "v65", 3)                                \
-	DFA_R0(3, "v41", 3) DFA_R1(2, "v49", 3) DFA_R2(1, "v57", 3) DFA_R3(0, "v65", 3)
-// loads of a piece (8 bytes per chain) into the registers W (current) or N (next): chain j at offset 512 j
-#define DFA_LOAD1(r0) "global_load_dwordx2 v[" r0 "], %[voff], %[src]\n"
-#define DFA_LOAD2(r0, r1) DFA_LOAD1(r0) "global_load_dwordx2 v[" r1 "], %[voff], %[src] offset:512\n"
-#define DFA_LOAD4(r0, r1, r2, r3)                                                                       \
-	DFA_LOAD2(r0, r1) "global_load_dwordx2 v[" r2 "], %[voff], %[src] offset:1024\n"                    \
-	                  "global_load_dwordx2 v[" r3 "], %[voff], %[src] offset:1536\n"
-#define DFA_SWAP1 "v_mov_b32 v40, v42\n v_mov_b32 v41, v43\n"
-#define DFA_SWAP2 DFA_SWAP1 "v_mov_b32 v48, v50\n v_mov_b32 v49, v51\n"
-#define DFA_SWAP4 DFA_SWAP2 "v_mov_b32 v56, v58\n v_mov_b32 v57, v59\n v_mov_b32 v64, v66\n v_mov_b32 v65, v67\n"
-// The loop over the pieces of one wave block, from piece p on; left when the pieces are done or a
-// stream batch may not take another piece's events (the C++ around it opens the next batch and
-// comes back).  LOADW / LOADN / BODY / SWAP: the forms above for the number of chains; STEP = 512 * chains.
-#ifdef DFA_EXP_NOLOG
-#define DFA_PIECE_WAIT(STORES) "s_waitcnt vmcnt(0)\n"
-#else
-#define DFA_PIECE_WAIT(STORES) "s_waitcnt vmcnt(" #STORES ")\n" /* (in issue order: the piece came before the body's stores, one per step) */
-#endif
-#define DFA_LOOP(LOADW, LOADN, BODY, SWAP, STEP, STORES)                                                        \
-	DFA_ASM_MACROS                                                                                      \
-	"s_mov_b64 s[38:39], exec\n"                                                                        \
-	"s_mov_b32 s55, m0\n"                               /* (the rare path borrows m0) */                 \
-	"v_mov_b32 v32, %[stride]\n"                                                                        \
-	"v_mov_b32 v33, 0x7f\n"                                                                             \
-	"v_mov_b32 v34, 1\n"                                                                                \
-	LOADW                                                                                               \
-	"s_waitcnt vmcnt(0)\n"                                                                              \
-	".Lpiece%=:\n"                                                                                      \
-	"s_add_u32 s54, %[p], 1\n"                                                                          \
-	"s_cmp_lt_u32 s54, %[pieces]\n"                                                                     \
-	"s_cbranch_scc0 .Lnopf%=\n"                                                                         \
-	"v_add_u32 %[voff], " #STEP ", %[voff]\n"           /* the next piece, under way during this one */ \
-	LOADN                                                                                               \
-	".Lnopf%=:\n"                                                                                       \
-	BODY                                                                                                \
-	DFA_PIECE_WAIT(STORES)                                                                              \
-	SWAP                                                                                                \
-	"s_mov_b32 %[p], s54\n"                                                                             \
-	"s_cmp_ge_u32 %[p], %[pieces]\n"                                                                    \
-	"s_cbranch_scc1 .Lout%=\n"                                                                          \
-	"s_cmp_gt_u32 %[curm], %[high]\n"                                                                   \
-	"s_cbranch_scc1 .Lout%=\n"                                                                          \
-	"s_cmp_gt_u32 %[cura], %[high]\n"                                                                   \
-	"s_cbranch_scc0 .Lpiece%=\n"                                                                        \
-	".Lout%=:\n"                                                                                        \
-	"s_mov_b32 m0, s55\n"                                                                               \
-	"s_mov_b64 exec, s[38:39]\n"                                                                        \
-	".purgem DFA_ISSUE\n"                                                                               \
-	".purgem DFA_RESOLVE\n"
-#define DFA_CLOBBERS                                                                                    \
-	"v20", "v21", "v32", "v33", "v34", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51",  \
-	    "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67",    \
-	    "v68", "v69", "v70", "v71", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49",    \
-	    "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "vcc", "scc", "memory"
+// dfa_scan_loop.inc is written by tools/gen_dfa_asm.py: the loop over the pieces of one wave block
+// for 1, 2 and 4 chains per lane, the chains interleaved instruction by instruction (exec all ones
+// throughout; lanes without an event store to a trash entry at the end of the batch; scalar masks per
+// chain; rare paths -- the global array, event indices beyond LDS, arrivals -- out of line).  The
+// schedule, the register plan and the reasons are in the generator.
+#include "dfa_scan_loop.inc"
 
 template <int C>
 __global__ void __launch_bounds__(1024) dfa_scan_asm_kernel(DfaDev A, DfaWork W, StreamDev Qm, StreamDev Qa, OutInit I) {
@@ -448,19 +265,20 @@ __global__ void __launch_bounds__(1024) dfa_scan_asm_kernel(DfaDev A, DfaWork W,
 	lm.open_own(Qm, wave_id);
 	la.open_own(Qa, wave_id);
 	const uint32_t pieces = uni32(W.range_bytes / 8);
-	const uint32_t hot_slots = uni32(A.hot_slots), lbits = uni32(A.label_bits), stride = A.stride;
-	constexpr uint32_t kHighBytes = (kDfaBatchEntries - 8 * C * 64) * 2;
-	const unsigned long long slot_p = uni64((unsigned long long)(uintptr_t)A.slot), crow_p = uni64((unsigned long long)(uintptr_t)A.crow);
+	const uint32_t hot_slots = uni32(A.hot_slots), stride = A.stride;
+	// (a step's store also writes the entry behind its events: one more than a piece's events must fit)
+	constexpr uint32_t kHighBytes = (kDfaBatchEntries - 8 - 8 * C * 64) * 2;
+	const unsigned long long slot_p = uni64((unsigned long long)(uintptr_t)A.slot), gof_p = uni64((unsigned long long)(uintptr_t)A.gof);
 	const unsigned long long cmiss_p = uni64((unsigned long long)(uintptr_t)W.cold_miss), carr_p = uni64((unsigned long long)(uintptr_t)W.cold_arr);
+	const unsigned long long chit_p = uni64((unsigned long long)(uintptr_t)W.cold_hit);
+	const uint32_t cold_base = A.cold_base, cold_base_s = uni32(A.cold_base);
 
 	for (uint32_t wb = wave_id; wb < W.nwb; wb += total_waves) {
-		uint32_t S[4] = {0, 0, 0, 0}, U[4] = {0, 0, 0, 0};
-		unsigned long long uc[4] = {0, 0, 0, 0}; // lanes whose event index lies beyond the LDS array
+		uint32_t S[4] = {0, 0, 0, 0}, G[4] = {0, 0, 0, 0};
 #pragma unroll
 		for (int j = 0; j < C; j++) {
 			const uint2 e = W.entry[(wb * C + j) * 64 + lane];
-			S[j] = e.x, U[j] = e.y;
-			uc[j] = uni64(__builtin_amdgcn_ballot_w64(e.y >= hot_slots));
+			S[j] = e.x, G[j] = e.y;
 		}
 		const unsigned long long src = uni64((unsigned long long)(uintptr_t)(W.tcodes + (size_t)wb * pieces * C * 64));
 		uint32_t p = 0;
@@ -470,21 +288,17 @@ __global__ void __launch_bounds__(1024) dfa_scan_asm_kernel(DfaDev A, DfaWork W,
 			const unsigned long long basem = uni64((unsigned long long)(uintptr_t)lm.base), basea = uni64((unsigned long long)(uintptr_t)la.base);
 			uint32_t pp = uni32(p);
 #define DFA_OPERANDS                                                                                                         \
-	[p] "+s"(pp), [curm] "+s"(curm), [cura] "+s"(cura), [voff] "+v"(voff), [S0] "+v"(S[0]), [U0] "+v"(U[0]), [UC0] "+s"(uc[0]),       \
-	    [S1] "+v"(S[1]), [U1] "+v"(U[1]), [UC1] "+s"(uc[1]), [S2] "+v"(S[2]), [U2] "+v"(U[2]), [UC2] "+s"(uc[2]), [S3] "+v"(S[3]),    \
-	    [U3] "+v"(U[3]), [UC3] "+s"(uc[3])                                                                                            \
-	    : [src] "s"(src), [pieces] "s"(pieces), [hot] "s"(hot_slots), [lbits] "s"(lbits), [high] "s"(kHighBytes),                    \
-	      [basem] "s"(basem), [basea] "s"(basea), [slot] "s"(slot_p), [crow] "s"(crow_p), [cmiss] "s"(cmiss_p),                      \
-	      [carr] "s"(carr_p), [stride] "v"(stride)                                                                                    \
-	    : DFA_CLOBBERS
+	[p] "+s"(pp), [curm] "+s"(curm), [cura] "+s"(cura), [voff] "+v"(voff), [S0] "+v"(S[0]), [G0] "+v"(G[0]), [S1] "+v"(S[1]),         \
+	    [G1] "+v"(G[1]), [S2] "+v"(S[2]), [G2] "+v"(G[2]), [S3] "+v"(S[3]), [G3] "+v"(G[3])                                           \
+	    : [src] "s"(src), [pieces] "s"(pieces), [hot] "s"(hot_slots), [high] "s"(kHighBytes), [basem] "s"(basem),                    \
+	      [basea] "s"(basea), [slot] "s"(slot_p), [gof] "s"(gof_p), [cmiss] "s"(cmiss_p), [carr] "s"(carr_p), [chit] "s"(chit_p),    \
+	      [stride] "v"(stride), [coldb] "v"(cold_base), [coldbs] "s"(cold_base_s)
 			if constexpr (C == 1) {
-				asm volatile(DFA_LOOP(DFA_LOAD1("40:41"), DFA_LOAD1("42:43"), DFA_BODY1, DFA_SWAP1, 512, 8) : DFA_OPERANDS);
+				asm volatile(DFA_GEN_LOOP1 : DFA_OPERANDS : DFA_GEN_CLOBBERS1);
 			} else if constexpr (C == 2) {
-				asm volatile(DFA_LOOP(DFA_LOAD2("40:41", "48:49"), DFA_LOAD2("42:43", "50:51"), DFA_BODY2, DFA_SWAP2, 1024, 16) : DFA_OPERANDS);
+				asm volatile(DFA_GEN_LOOP2 : DFA_OPERANDS : DFA_GEN_CLOBBERS2);
 			} else {
-				asm volatile(DFA_LOOP(DFA_LOAD4("40:41", "48:49", "56:57", "64:65"), DFA_LOAD4("42:43", "50:51", "58:59", "66:67"),
-				                      DFA_BODY4, DFA_SWAP4, 2048, 32)
-				             : DFA_OPERANDS);
+				asm volatile(DFA_GEN_LOOP4 : DFA_OPERANDS : DFA_GEN_CLOBBERS4);
 			}
 #undef DFA_OPERANDS
 			p = pp;
@@ -493,7 +307,7 @@ __global__ void __launch_bounds__(1024) dfa_scan_asm_kernel(DfaDev A, DfaWork W,
 			if (la.cur * 2 > kHighBytes) la.roll(Qa, lane);
 		}
 #pragma unroll
-		for (int j = 0; j < C; j++) W.exit_a[(wb * C + j) * 64 + lane] = uint2{S[j] & (kBaseMask | A.inc_bit), U[j]};
+		for (int j = 0; j < C; j++) W.exit_a[(wb * C + j) * 64 + lane] = uint2{S[j] & (kBaseMask | kPartial), G[j]};
 	}
 	lm.close(Qm, lane);
 	la.close(Qa, lane);
@@ -513,21 +327,26 @@ __device__ __forceinline__ void book_event(const DfaDev &A, uint32_t ev, long lo
 	atomicAdd(&out[total_index], (unsigned long long)(n * (long long)len));
 }
 
-// the counters of the events beyond the LDS array; cleared here for the next evaluation
-__global__ void __launch_bounds__(256) dfa_cold_reduce_kernel(DfaDev A, uint32_t *cold_miss, uint32_t *cold_arr,
-                                                              unsigned long long *out, uint32_t total_index) {
-	const uint32_t n = A.nslots - A.hot_slots;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		const uint32_t m = cold_miss[i], a = cold_arr[i];
-		if (m) {
-			book_event(A, A.ev_miss[A.hot_slots + i], (long long)m, out, total_index);
-			cold_miss[i] = 0;
-		}
-		if (a) {
-			book_event(A, A.ev_arr[A.hot_slots + i], (long long)a, out, total_index);
-			cold_arr[i] = 0;
-		}
+// as book_event, the total left to the caller: returns the tokens the event stands for, times n
+__device__ __forceinline__ long long book_event_ids(const DfaDev &A, uint32_t ev, long long n, unsigned long long *out) {
+	if (ev == kEvNone || n == 0) return 0;
+	if (!(ev & kEvList)) {
+		atomicAdd(&out[ev], (unsigned long long)n);
+		return n;
 	}
+	const uint32_t o = ev & ~kEvList, len = A.pool[o];
+	for (uint32_t i = 0; i < len; i++) atomicAdd(&out[A.pool[o + 1 + i]], (unsigned long long)n);
+	return n * (long long)len;
+}
+// one atomic per workgroup for the tokens its threads booked (every thread of the workgroup calls this)
+__device__ __forceinline__ void add_block_total(long long mine, unsigned long long *out, uint32_t total_index) {
+	__shared__ long long s_block_total;
+	if (threadIdx.x == 0) s_block_total = 0;
+	__syncthreads();
+	for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+	if ((threadIdx.x & 63) == 0 && mine != 0) atomicAdd((unsigned long long *)&s_block_total, (unsigned long long)mine);
+	__syncthreads();
+	if (threadIdx.x == 0 && s_block_total != 0) atomicAdd(&out[total_index], (unsigned long long)s_block_total);
 }
 
 // ---- range entries: fix-up -----------------------------------------------------------------------
@@ -544,47 +363,40 @@ struct DfaFix {
 	uint32_t blocks;
 };
 
-__device__ __forceinline__ void dfa_step_global(const DfaFix &F, uint32_t &S, uint32_t &U, uint32_t c, long long sign) {
-	const uint32_t lmask = (1u << F.A.label_bits) - 1;
-	const uint32_t b = S & kBaseMask, t = b + c;
-	uint32_t x, id = t;
-	bool hit;
-	if (t < F.A.hot_slots) {
-		x = F.A.hot[t];
-		hit = ((x >> 24) & lmask) == c;
-		if (!hit && (S & F.A.inc_bit) != 0) {
-			id = F.A.crow[b] + c;
-			x = F.A.slot[id];
-			hit = ((x >> 24) & lmask) == c;
-		}
+// Two range boundaries' states are the same when their words are and, under cold_base, their global bases (the
+// global base a lane carries outside cold_base is whatever it last loaded: it says nothing)
+__device__ __forceinline__ bool dfa_same_state(const DfaDev &A, uint2 a, uint2 b) {
+	return a.x == b.x && ((a.x & kBaseMask) != A.cold_base || a.y == b.y);
+}
+
+__device__ __forceinline__ void dfa_step_global(const DfaFix &F, uint32_t &S, uint32_t &G, uint32_t c, long long sign) {
+	DfaStep r = dfa_step(F.A, F.A.hot, S, G, c);
+	if (r.second_look) dfa_second_look(F.A, r, S, G, c);
+	if (r.hit) {
+		if (r.x & kArr) book_event(F.A, F.A.ev_arr[r.id], sign, F.out, F.total_index);
+		S = r.x & (kBaseMask | kPartial);
+		G = r.g_next;
 	} else {
-		x = F.A.slot[t];
-		hit = ((x >> 24) & lmask) == c;
-	}
-	if (hit) {
-		if (x & kArr) book_event(F.A, F.A.ev_arr[id], sign, F.out, F.total_index);
-		S = x & (kBaseMask | F.A.inc_bit);
-		U = id;
-	} else {
-		book_event(F.A, F.A.ev_miss[U], sign, F.out, F.total_index);
+		book_event(F.A, F.A.ev_miss[dfa_key(F.A, S, G)], sign, F.out, F.total_index);
 		S = c * F.A.stride;
-		U = c;
 	}
 }
 
-// true when the two automata met inside the range (its exit stands); *exit_out = the true one's state at the end
+// true when the two automata met inside the range (its exit stands); *exit_out = the true one's state at the end.
+// (Two states are the same when their words are and, under cold_base, their global bases.)
 __device__ bool dfa_dual_walk(const DfaFix &F, uint32_t g, uint2 want, uint2 have, uint2 *exit_out) {
-	const uint32_t keep = kBaseMask | F.A.inc_bit;
-	uint32_t Sa = want.x & keep, Ua = want.y, Sb = have.x & keep, Ub = have.y;
+	const uint32_t keep = kBaseMask | kPartial;
+	uint32_t Sa = want.x & keep, Ga = want.y, Sb = have.x & keep, Gb = have.y;
+	auto same = [&]() { return Sa == Sb && ((Sa & kBaseMask) != F.A.cold_base || Ga == Gb); };
 	const uint8_t *p = F.codes + (size_t)g * F.range_bytes;
 	for (uint32_t i = 0; i < F.range_bytes; i++) {
-		if (Sa == Sb && Ua == Ub) return true;
+		if (same()) return true;
 		const uint32_t c = p[i];
-		dfa_step_global(F, Sa, Ua, c, 1);
-		dfa_step_global(F, Sb, Ub, c, -1);
+		dfa_step_global(F, Sa, Ga, c, 1);
+		dfa_step_global(F, Sb, Gb, c, -1);
 	}
-	*exit_out = uint2{Sa, Ua};
-	return Sa == Sb && Ua == Ub;
+	*exit_out = uint2{Sa, Ga};
+	return same();
 }
 
 __device__ __forceinline__ uint2 dfa_exit_now(const DfaFix &F, uint32_t g) {
@@ -601,8 +413,7 @@ __device__ void dfa_fixup_ordered(const DfaFix &F) {
 			const uint32_t g = base + threadIdx.x;
 			bool need = false;
 			if (g < F.nranges) {
-				const uint2 w = dfa_exit_now(F, g - 1), h = F.entry[g];
-				need = w.x != h.x || w.y != h.y;
+				need = !dfa_same_state(F.A, dfa_exit_now(F, g - 1), F.entry[g]);
 			}
 			if (threadIdx.x == 0) s_first = 0xFFFFFFFFu;
 			__syncthreads();
@@ -626,14 +437,14 @@ __device__ void dfa_fixup_ordered(const DfaFix &F) {
 	}
 }
 
-__global__ void __launch_bounds__(256) dfa_fixup_kernel(DfaFix F) {
+__device__ void dfa_fixup_body(const DfaFix &F) {
 	__shared__ uint32_t s_last, s_wrote;
 	if (threadIdx.x == 0) s_wrote = 0;
 	__syncthreads();
 	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < F.nranges; g += F.blocks * blockDim.x) {
 		if (g == 0) continue;
 		const uint2 want = F.exit_a[g - 1], have = F.entry[g];
-		if (want.x != have.x || want.y != have.y) {
+		if (!dfa_same_state(F.A, want, have)) {
 			uint2 ex;
 			if (!dfa_dual_walk(F, g, want, have, &ex)) {
 				F.exit_b[g] = ex;
@@ -653,6 +464,196 @@ __global__ void __launch_bounds__(256) dfa_fixup_kernel(DfaFix F) {
 	if (!s_last) return;
 	dfa_fixup_ordered(F);
 }
+
+// ---- streams -> counts: two launches per evaluation ------------------------------------------------
+// dfa_hist_kernel: workgroups [0, split) bin the miss stream (keys = LDS bases of the states left),
+// workgroups [split, gridDim.x) the arrival stream (keys = LDS entries arrived on), each into LDS and
+// then into a slab row of 16 bits per key (as hist_slots_kernel, kernels_stream.hip, whose loop this
+// is); the evaluation's fix-up of the range entries rides along in the first workgroups (with an
+// unchanged vocabulary it only compares: a launch of its own costs more).
+__global__ void __launch_bounds__(1024) dfa_hist_kernel(DfaDev A, StreamDev Qm, StreamDev Qa, int16_t *slab, uint32_t split, DfaFix F,
+                                                        unsigned long long *out, uint32_t total_index) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char dfa_hist_smem[];
+	uint32_t *bins = reinterpret_cast<uint32_t *>(dfa_hist_smem);
+	if (F.blocks != 0 && blockIdx.x < F.blocks) dfa_fixup_body(F);
+	const bool arrivals = blockIdx.x >= split;
+	const StreamDev &Q = arrivals ? Qa : Qm;
+	const uint32_t nblk = arrivals ? gridDim.x - split : split, bidx = arrivals ? blockIdx.x - split : blockIdx.x;
+	const uint32_t width = A.hot_slots;
+	for (uint32_t i = threadIdx.x; i < width + 64; i += blockDim.x) bins[i] = 0;
+	__syncthreads();
+	uint32_t batches = Q.cursor[0];
+	if (batches > Q.capacity_batches) batches = Q.capacity_batches;
+	constexpr uint32_t vecs_per_block = 512 * 2 / 16; // 64: one 1 KiB row per block of a batch
+	constexpr int kRowsInFlight = 8;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t n_waves = nblk * (blockDim.x / 64);
+	const uint32_t wave_id = uni32(bidx * (blockDim.x / 64) + (threadIdx.x >> 6));
+	const uint4 *vec = reinterpret_cast<const uint4 *>(Q.blocks);
+	const uint32_t spare = width + lane; // where entries past a batch's fill go: a word of the lane's own, never read
+	auto blank = [&](uint4 v, uint32_t first, uint32_t live) { // a batch's last, partly written vector: what lies past `live` to 0xFFFF
+		if (first + 8 <= live) return v;
+		uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		for (uint32_t q = 0; q < 8; q++)
+			if (first + q >= live) w[q >> 1] |= 0xFFFFu << (16 * (q & 1));
+		return uint4{w[0], w[1], w[2], w[3]};
+	};
+	auto count8 = [&](const uint4 &v) {
+		const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const uint32_t e0 = wds[k] & 0xFFFFu, e1 = wds[k] >> 16;
+			atomicAdd(&bins[e0 < spare ? e0 : spare], 1u);
+			atomicAdd(&bins[e1 < spare ? e1 : spare], 1u);
+		}
+	};
+	if (!arrivals) {
+		// rows first, first + step, ... of a batch, eight in flight
+		auto some_rows = [&](uint32_t bt, uint32_t first_row, uint32_t step) {
+			uint32_t live = Q.fill[bt]; // entries written to the batch (what follows them was never written, or is not counted)
+			if (live > kDfaBatchEntries) live = kDfaBatchEntries;
+			live = uni32(live);
+			const uint32_t live_rows = (live + 511) / 512;
+			const uint4 *rows = vec + (uint64_t)bt * kStreamBatch * vecs_per_block + lane;
+			for (uint32_t r0 = first_row; r0 < live_rows; r0 += kRowsInFlight * step) {
+				uint4 v[kRowsInFlight];
+#pragma unroll
+				for (int u = 0; u < kRowsInFlight; u++) {
+					const uint32_t r = r0 + u * step;
+					v[u] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+					if (r < live_rows) v[u] = blank(rows[(size_t)r * 64], r * 512 + lane * 8, live);
+				}
+#pragma unroll
+				for (int u = 0; u < kRowsInFlight; u++)
+					if (r0 + u * step < live_rows) count8(v[u]);
+			}
+		};
+		// The scan's waves own a batch each and 248 workgroups' waves are fewer than that: a wave takes the batch
+		// of its number, and the batches left over are split by rows among all waves (handing batches out by an
+		// atomic counter was tried: 4,000 waves on one address took 45 us).
+		if (wave_id < batches) some_rows(wave_id, 0, 1);
+		const uint32_t tail = batches > n_waves ? batches - n_waves : 0u;
+		if (tail != 0 && tail <= n_waves) {
+			const uint32_t per = n_waves / tail, tb = wave_id / per;
+			if (tb < tail) some_rows(n_waves + tb, wave_id % per, per);
+		} else {
+			for (uint32_t bt = n_waves + wave_id; tail != 0 && bt < batches; bt += n_waves) some_rows(bt, 0, 1);
+		}
+	} else {
+		// the arrival stream: a batch per wave of the scan, a few dozen entries in most -- eight batches in flight, row by row
+		for (uint32_t b0 = wave_id; b0 < batches; b0 += kRowsInFlight * n_waves) {
+			uint32_t live[kRowsInFlight], most = 0;
+#pragma unroll
+			for (int u = 0; u < kRowsInFlight; u++) {
+				const uint32_t bt = b0 + u * n_waves;
+				live[u] = bt < batches ? Q.fill[bt] : 0u;
+			}
+#pragma unroll
+			for (int u = 0; u < kRowsInFlight; u++) {
+				if (live[u] > kDfaBatchEntries) live[u] = kDfaBatchEntries;
+				live[u] = uni32(live[u]);
+				most = live[u] > most ? live[u] : most;
+			}
+			for (uint32_t r = 0; r * 512 < most; r++) {
+				uint4 v[kRowsInFlight];
+#pragma unroll
+				for (int u = 0; u < kRowsInFlight; u++) {
+					v[u] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+					if (r * 512 < live[u])
+						v[u] = blank(vec[((uint64_t)(b0 + u * n_waves) * kStreamBatch + r) * vecs_per_block + lane], r * 512 + lane * 8, live[u]);
+				}
+#pragma unroll
+				for (int u = 0; u < kRowsInFlight; u++)
+					if (r * 512 < live[u]) count8(v[u]);
+			}
+		}
+	}
+	__syncthreads();
+	// the slab row: 16 bits per key; a bin that does not fit goes to the output directly, as the reduction would have booked it
+	int16_t *row = slab + (size_t)blockIdx.x * ((width + 1) & ~1u);
+	const uint32_t *ev = arrivals ? A.ev_arr : A.ev_miss;
+	for (uint32_t i = threadIdx.x; i < width; i += blockDim.x) {
+		const uint32_t n = bins[i];
+		const bool fits = n <= 32767u;
+		row[i] = fits ? (int16_t)n : (int16_t)0;
+		if (!fits) book_event(A, ev[i], (long long)n, out, total_index);
+	}
+}
+
+// dfa_reduce_kernel: the slab rows' column sums through the event tables into the output (workgroups
+// [0, colgroups): 128 keys each, rows [0, split) miss events, [split, rows) arrivals); the counters of the
+// keys and entries of the global array, cleared for the next evaluation (the workgroups after them);
+// and the streams' cursors and the fix-up's words back to their start.
+constexpr uint32_t kDfaReduceGroups = 16;
+__global__ void __launch_bounds__(1024) dfa_reduce_kernel(DfaDev A, const int16_t *slab, uint32_t split, uint32_t rows, uint32_t colgroups,
+                                                          uint32_t *cold_miss, uint32_t *cold_arr, StreamDev Qm, StreamDev Qa,
+                                                          uint32_t first_batches, uint32_t *changed, unsigned long long *out,
+                                                          uint32_t total_index) {
+	__shared__ int part[kDfaReduceGroups][64][4];
+	if (blockIdx.x == 0 && threadIdx.x == 0) { // (the histogram has read the cursors, the fix-up is done with its words)
+		if (Qa.cursor[1]) Qm.cursor[1] = 1u; // one overflow word for the host
+		Qm.cursor[0] = first_batches, Qa.cursor[0] = first_batches, Qa.cursor[1] = 0u;
+		changed[0] = changed[1] = 0u;
+	}
+	if (blockIdx.x >= colgroups) {
+		const uint32_t n = A.nslots - A.hot_slots;
+		long long mine = 0;
+		for (uint32_t i = (blockIdx.x - colgroups) * blockDim.x + threadIdx.x; i < n; i += (gridDim.x - colgroups) * blockDim.x) {
+			const uint32_t m = cold_miss[i], a = cold_arr[i];
+			if (m) {
+				mine += book_event_ids(A, A.ev_miss[A.hot_slots + i], (long long)m, out);
+				cold_miss[i] = 0;
+			}
+			if (a) {
+				mine += book_event_ids(A, A.ev_arr[A.hot_slots + i], (long long)a, out);
+				cold_arr[i] = 0;
+			}
+		}
+		add_block_total(mine, out, total_index);
+		return;
+	}
+	const uint32_t lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+	const uint32_t k = blockIdx.x * 128 + lane * 2;
+	const uint32_t width = A.hot_slots;
+	const size_t stride = ((width + 1) & ~1u) / 2; // in 32-bit words
+	const uint32_t *slab2 = reinterpret_cast<const uint32_t *>(slab);
+	int acc[4] = {0, 0, 0, 0}; // miss lo / hi, arrival lo / hi (rows x 32,767 fits easily)
+	if (k < width) {
+		uint32_t r = grp;
+		for (; r + 3 * kDfaReduceGroups < split; r += 4 * kDfaReduceGroups) { // (four rows in flight: the loop waits on memory, not on adds)
+			const uint32_t a0 = slab2[(size_t)r * stride + k / 2];
+			const uint32_t a1 = slab2[(size_t)(r + kDfaReduceGroups) * stride + k / 2];
+			const uint32_t a2 = slab2[(size_t)(r + 2 * kDfaReduceGroups) * stride + k / 2];
+			const uint32_t a3 = slab2[(size_t)(r + 3 * kDfaReduceGroups) * stride + k / 2];
+			acc[0] += (int)(a0 & 0xFFFFu) + (int)(a1 & 0xFFFFu) + (int)(a2 & 0xFFFFu) + (int)(a3 & 0xFFFFu);
+			acc[1] += (int)(a0 >> 16) + (int)(a1 >> 16) + (int)(a2 >> 16) + (int)(a3 >> 16);
+		}
+		for (; r < rows; r += kDfaReduceGroups) {
+			const uint32_t a = slab2[(size_t)r * stride + k / 2];
+			const int o = r < split ? 0 : 2;
+			acc[o] += (int)(a & 0xFFFFu);
+			acc[o + 1] += (int)(a >> 16);
+		}
+	}
+#pragma unroll
+	for (int q = 0; q < 4; q++) part[grp][lane][q] = acc[q];
+	__syncthreads();
+	long long mine = 0;
+	if (grp == 0 && k < width) {
+		for (uint32_t g = 1; g < kDfaReduceGroups; g++)
+#pragma unroll
+			for (int q = 0; q < 4; q++) acc[q] += part[g][lane][q];
+		mine += book_event_ids(A, A.ev_miss[k], acc[0], out);
+		mine += book_event_ids(A, A.ev_arr[k], acc[2], out);
+		if (k + 1 < width) {
+			mine += book_event_ids(A, A.ev_miss[k + 1], acc[1], out);
+			mine += book_event_ids(A, A.ev_arr[k + 1], acc[3], out);
+		}
+	}
+	add_block_total(mine, out, total_index);
+}
+
+__global__ void __launch_bounds__(256) dfa_fixup_kernel(DfaFix F) { dfa_fixup_body(F); }
 
 } // namespace
 
@@ -709,19 +710,28 @@ void launch_dfa_scan(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, con
 	}
 }
 
-void launch_dfa_fixup(const DfaDev &A, const DfaWork &W, const uint8_t *codes, uint32_t *changed, uint32_t epoch,
-                      unsigned long long *out, uint32_t total_index, hipStream_t stream) {
-	if (W.nranges < 2) return;
-	const uint32_t blocks = std::min<uint32_t>((W.nranges + 255) / 256, 64);
-	DfaFix F{A, codes, W.range_bytes, W.nranges, W.entry, W.exit_a, W.exit_b, W.exit_tag, changed, epoch, out, total_index, blocks};
-	hipLaunchKernelGGL(dfa_fixup_kernel, dim3(blocks), dim3(256), 0, stream, F);
-}
-
-void launch_dfa_cold_reduce(const DfaDev &A, const DfaWork &W, unsigned long long *out, uint32_t total_index, hipStream_t stream) {
-	const uint32_t n = A.nslots - A.hot_slots;
-	if (n == 0) return;
-	hipLaunchKernelGGL(dfa_cold_reduce_kernel, dim3(std::min<uint32_t>((n + 255) / 256, 2048)), dim3(256), 0, stream, A, W.cold_miss,
-	                   W.cold_arr, out, total_index);
+void launch_dfa_count(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, const StreamDev &Qa, const uint8_t *codes,
+                      uint32_t *changed, uint32_t epoch, unsigned long long *out, uint32_t total_index, uint32_t *slab,
+                      uint32_t miss_blocks, uint32_t arrival_blocks, uint32_t first_batches, hipStream_t stream) {
+	DfaFix F{};
+	if (W.nranges >= 2) {
+		const uint32_t blocks = std::min<uint32_t>(std::min<uint32_t>((W.nranges + 1023) / 1024, 64), miss_blocks);
+		F = DfaFix{A, codes, W.range_bytes, W.nranges, W.entry, W.exit_a, W.exit_b, W.exit_tag, changed, epoch, out, total_index, blocks};
+	}
+	StreamDev Qa2 = Qa, Qm2 = Qm;
+	if (getenv("TOKSCORE_DBG_NOARRHIST")) Qa2.capacity_batches = 0; // (debugging: timing only)
+	if (getenv("TOKSCORE_DBG_NOMISSHIST")) Qm2.capacity_batches = 0;
+	if (getenv("TOKSCORE_DBG_NOFIX")) F.blocks = 0;
+	const uint32_t lds = (A.hot_slots + 64) * 4; // + a spare word per lane
+	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dfa_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	int16_t *rows = reinterpret_cast<int16_t *>(slab);
+	hipLaunchKernelGGL(dfa_hist_kernel, dim3(miss_blocks + arrival_blocks), dim3(1024), lds, stream, A, Qm2, Qa2, rows, miss_blocks, F, out,
+	                   total_index);
+	const uint32_t colgroups = (A.hot_slots + 127) / 128;
+	const uint32_t ncold = A.nslots - A.hot_slots;
+	const uint32_t coldblocks = std::min<uint32_t>((ncold + 1023) / 1024, 256);
+	hipLaunchKernelGGL(dfa_reduce_kernel, dim3(colgroups + coldblocks), dim3(64 * kDfaReduceGroups), 0, stream, A, rows, miss_blocks,
+	                   miss_blocks + arrival_blocks, colgroups, W.cold_miss, W.cold_arr, Qm, Qa, first_batches, changed, out, total_index);
 }
 
 bool plan_dfa_scan(uint32_t hot_slots, uint64_t prep_total, uint32_t num_cus, uint32_t chains_hint, DfaScanPlan *plan) {

@@ -239,8 +239,9 @@ struct tokscore_ctx {
 	uint64_t dfa_max_slots = 6u << 20;
 	uint32_t dfa_chains = 0;
 	uint32_t dfa_lds_cap = 0;
+	bool dfa_relayout_on = true;   // TOKSCORE_DFA_RELAYOUT=0: what LDS holds stays as the host's sample chose it
 	DfaScanPlan dplan = {};
-	uint32_t *d_dhot = nullptr, *d_dcrow = nullptr, *d_dslot = nullptr, *d_dev_miss = nullptr, *d_dev_arr = nullptr, *d_dpool = nullptr;
+	uint32_t *d_dhot = nullptr, *d_dgof = nullptr, *d_dslot = nullptr, *d_dev_miss = nullptr, *d_dev_arr = nullptr, *d_dpool = nullptr;
 	uint8_t *d_dcodes = nullptr;   // the prepared corpus in the automaton's codes, linear
 	void *d_dtcodes = nullptr;     // ... transposed for the scan
 	uint2 *d_dstate = nullptr;     // entry | exit_a | exit_b
@@ -254,6 +255,11 @@ struct tokscore_ctx {
 	uint32_t dslab_blocks = 0;
 	uint32_t dfa_epoch = 0;
 	bool dfa_used_last = false;    // the last full evaluation ran on the automaton scan
+	// what LDS holds is chosen again after a plan's first evaluations, from the scan's own counters
+	std::vector<uint32_t> dfa_prior; // uses of the builder's entries that LDS did not hold (DfaOptions::prior)
+	uint32_t dfa_evals = 0;          // evaluations on the image as it is
+	uint32_t dfa_relayouts = 0;      // images built from counters (at most kDfaRelayouts per vocabulary state)
+	uint64_t dfa_second_hits = 0;    // lookups the global array answered with a hit, in the evaluations counted last
 	double dfa_build_ms = 0, dfa_plan_ms = 0;
 
 	// outputs
@@ -340,7 +346,7 @@ int build_prepared(tokscore_ctx *c) {
 }
 
 void free_dfa(tokscore_ctx *c) {
-	void **bufs[] = {(void **)&c->d_dhot, (void **)&c->d_dcrow, (void **)&c->d_dslot, (void **)&c->d_dev_miss, (void **)&c->d_dev_arr, (void **)&c->d_dpool, (void **)&c->d_dcodes,
+	void **bufs[] = {(void **)&c->d_dhot, (void **)&c->d_dgof, (void **)&c->d_dslot, (void **)&c->d_dev_miss, (void **)&c->d_dev_arr, (void **)&c->d_dpool, (void **)&c->d_dcodes,
 	                 &c->d_dtcodes, (void **)&c->d_dstate, (void **)&c->d_dtag, (void **)&c->d_dcold, &c->d_dstream_m, &c->d_dstream_a,
 	                 (void **)&c->d_dfill_m, (void **)&c->d_dfill_a, (void **)&c->d_dcursor, (void **)&c->d_dslab};
 	for (void **b : bufs) {
@@ -349,6 +355,9 @@ void free_dfa(tokscore_ctx *c) {
 	}
 	c->dfa_state = 0;
 	c->dfa_used_last = false;
+	c->dfa_prior.clear();
+	c->dfa_evals = c->dfa_relayouts = 0;
+	c->dfa_second_hits = 0;
 }
 
 void free_plan(tokscore_ctx *c) {
@@ -852,26 +861,28 @@ bool upload_dfa_image(tokscore_ctx *c) {
 	opt.lds_slots = dfa_lds_slots_max(c->dfa_lds_cap);
 	opt.sample = c->sample.empty() ? nullptr : c->sample.data();
 	opt.sample_bytes = c->sample.size();
+	opt.corpus_bytes = c->total + c->D;
+	if (!c->dfa_prior.empty()) opt.prior = c->dfa_prior.data(), opt.prior_entries = (uint32_t)c->dfa_prior.size();
 	std::string why;
 	const auto t0 = std::chrono::steady_clock::now();
 	if (!c->trie.BuildDfa(&c->dimg, opt, &why)) return false;
 	c->dfa_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	const DfaImage &g = c->dimg;
 	const size_t n = g.nslots, nh = g.hot_slots, ne = g.ev_miss.size();
-	for (uint32_t **b : {&c->d_dhot, &c->d_dcrow, &c->d_dslot, &c->d_dev_miss, &c->d_dev_arr, &c->d_dpool}) {
+	for (uint32_t **b : {&c->d_dhot, &c->d_dgof, &c->d_dslot, &c->d_dev_miss, &c->d_dev_arr, &c->d_dpool}) {
 		if (*b) (void)hipFree(*b);
 		*b = nullptr;
 	}
 	bool ok = hipMalloc((void **)&c->d_dhot, (nh + 16) * sizeof(uint32_t)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_dcrow, (nh + 16) * sizeof(uint32_t)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_dslot, (n + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dgof, (nh + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dslot, (2 * n + 16) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dev_miss, (ne + 16) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dev_arr, (ne + 16) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dpool, (g.pool.size() + 16) * sizeof(uint32_t)) == hipSuccess;
 	ok = ok && hipMemsetAsync(c->d_dhot + nh, 0xFF, 16 * sizeof(uint32_t), c->stream) == hipSuccess &&
 	     hipMemcpyAsync(c->d_dhot, g.hot.data(), nh * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-	     hipMemcpyAsync(c->d_dcrow, g.crow.data(), nh * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-	     hipMemcpyAsync(c->d_dslot, g.slot.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dgof, g.gof.data(), nh * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dslot, g.slot.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
 	     hipMemcpyAsync(c->d_dev_miss, g.ev_miss.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
 	     hipMemcpyAsync(c->d_dev_arr, g.ev_arr.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
 	     (g.pool.empty() || hipMemcpyAsync(c->d_dpool, g.pool.data(), g.pool.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess) &&
@@ -882,11 +893,10 @@ bool upload_dfa_image(tokscore_ctx *c) {
 
 DfaDev dfa_dev(const tokscore_ctx *c) {
 	DfaDev A;
-	A.hot = c->d_dhot, A.crow = c->d_dcrow, A.slot = c->d_dslot, A.ev_miss = c->d_dev_miss, A.ev_arr = c->d_dev_arr, A.pool = c->d_dpool;
+	A.hot = c->d_dhot, A.gof = c->d_dgof, A.slot = (const uint2 *)c->d_dslot, A.ev_miss = c->d_dev_miss, A.ev_arr = c->d_dev_arr, A.pool = c->d_dpool;
 	A.nslots = c->dimg.nslots;
 	A.hot_slots = c->dimg.hot_slots;
-	A.label_bits = c->dimg.label_bits;
-	A.inc_bit = c->dimg.inc_bit;
+	A.cold_base = c->dimg.cold_base;
 	A.stride = c->dimg.stride;
 	return A;
 }
@@ -903,6 +913,7 @@ DfaWork dfa_work(const tokscore_ctx *c) {
 	W.exit_tag = c->d_dtag;
 	W.cold_miss = c->d_dcold;
 	W.cold_arr = c->d_dcold + c->dimg.nslots + 1;
+	W.cold_hit = c->d_dcold + 2 * ((size_t)c->dimg.nslots + 1);
 	return W;
 }
 
@@ -912,7 +923,7 @@ void ensure_dfa(tokscore_ctx *c) {
 	if (c->dfa_state != 0) return;
 	c->dfa_state = -1;
 	const uint64_t prep_total = c->total + c->D;
-	if (!c->dfa_enabled || c->D == 0 || c->total == 0 || c->V + 5 >= 0x7FFFFFFFull || prep_total + kCorpusPad >= 0xFFFF0000ull) return;
+	if (!c->dfa_enabled || c->force_generic || c->D == 0 || c->total == 0 || c->V + 5 >= 0x7FFFFFFFull || prep_total + kCorpusPad >= 0xFFFF0000ull) return;
 	const auto t0 = std::chrono::steady_clock::now();
 	if (!upload_dfa_image(c)) return;
 	DfaScanPlan &P = c->dplan;
@@ -931,7 +942,7 @@ void ensure_dfa(tokscore_ctx *c) {
 	          hipMalloc(&c->d_dtcodes, covered) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dstate, 3 * nranges * sizeof(uint2)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dtag, nranges * sizeof(uint32_t)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_dcold, (2 * (size_t)ncold + 2) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dcold, (3 * (size_t)ncold + 3) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc(&c->d_dstream_m, cap * kStreamBatch * 1024) == hipSuccess &&
 	          hipMalloc(&c->d_dstream_a, cap * kStreamBatch * 1024) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dfill_m, cap * sizeof(uint32_t)) == hipSuccess &&
@@ -941,7 +952,7 @@ void ensure_dfa(tokscore_ctx *c) {
 	ok = ok && hipMemsetAsync(c->d_dcodes, 0, lin_bytes, c->stream) == hipSuccess &&
 	     hipMemsetAsync(d_flags, 0, sizeof(uint32_t), c->stream) == hipSuccess &&
 	     hipMemsetAsync(c->d_dtag, 0, nranges * sizeof(uint32_t), c->stream) == hipSuccess &&
-	     hipMemsetAsync(c->d_dcold, 0, (2 * (size_t)ncold + 2) * sizeof(uint32_t), c->stream) == hipSuccess &&
+	     hipMemsetAsync(c->d_dcold, 0, (3 * (size_t)ncold + 3) * sizeof(uint32_t), c->stream) == hipSuccess &&
 	     hipMemsetAsync(c->d_dcursor, 0, 16 * sizeof(uint32_t), c->stream) == hipSuccess;
 	if (ok) {
 		CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
@@ -950,6 +961,9 @@ void ensure_dfa(tokscore_ctx *c) {
 		launch_prep_corpus(C, M, c->d_dcodes, prep_total, d_flags, c->stream);
 		launch_dfa_transpose(c->d_dcodes, prep_total, P.range_bytes, P.chains, P.nwb, c->d_dtcodes, c->stream);
 		launch_dfa_reset_states(dfa_work(c), c->dimg.start_word(), c->stream);
+		launch_dfa_prepare(nullptr, (uint32_t)c->V, c->D, c->total, StreamDev{c->d_dstream_m, (uint32_t)cap, c->d_dfill_m, c->d_dcursor},
+		                   StreamDev{c->d_dstream_a, (uint32_t)cap, c->d_dfill_a, c->d_dcursor + 4}, P.blocks * P.waves_per_block,
+		                   c->d_dcursor + 8, c->stream);
 		ok = hipMemcpyAsync(&flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
 		     hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
 	}
@@ -968,9 +982,9 @@ void ensure_dfa(tokscore_ctx *c) {
 	c->dfa_plan_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// After toggles: a new image for the same corpus (the codes and the ranges stay: toggles do not change
-// the trie's edges), every range's entry back to a guess.
-bool refresh_dfa(tokscore_ctx *c) {
+// A new image for the same corpus (the codes and the ranges stay: neither toggles nor another choice of
+// what LDS holds change the trie's edges), every range's entry back to a guess.
+bool rebuild_dfa(tokscore_ctx *c) {
 	(void)hipDeviceSynchronize(); // (an evaluation on a caller's stream may still read what is replaced here)
 	const uint32_t old_codes = c->dimg.ncodes;
 	if (!upload_dfa_image(c) || c->dimg.ncodes != old_codes) return false;
@@ -984,9 +998,9 @@ bool refresh_dfa(tokscore_ctx *c) {
 	P.lds_bytes = ((lds + 3) & ~3u) * 4;
 	c->dplan = P;
 	const uint32_t ncold = c->dimg.nslots;
-	bool ok = hipMalloc((void **)&c->d_dcold, (2 * (size_t)ncold + 2) * sizeof(uint32_t)) == hipSuccess &&
+	bool ok = hipMalloc((void **)&c->d_dcold, (3 * (size_t)ncold + 3) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dslab, (size_t)c->dslab_blocks * (P.lds_slots + 2) * sizeof(uint32_t)) == hipSuccess &&
-	          hipMemsetAsync(c->d_dcold, 0, (2 * (size_t)ncold + 2) * sizeof(uint32_t), c->stream) == hipSuccess &&
+	          hipMemsetAsync(c->d_dcold, 0, (3 * (size_t)ncold + 3) * sizeof(uint32_t), c->stream) == hipSuccess &&
 	          hipMemsetAsync(c->d_dtag, 0, (size_t)P.nwb * 64 * P.chains * sizeof(uint32_t), c->stream) == hipSuccess;
 	if (!ok) {
 		(void)hipGetLastError();
@@ -996,7 +1010,46 @@ bool refresh_dfa(tokscore_ctx *c) {
 	c->dfa_version = c->toggle_version;
 	c->dfa_stale_evals = 0;
 	c->dfa_epoch = 0;
+	c->dfa_evals = 0;
 	return true;
+}
+
+// After toggles: the counters of the old vocabulary's entries say nothing about the new one's.
+bool refresh_dfa(tokscore_ctx *c) {
+	c->dfa_prior.clear();
+	c->dfa_relayouts = 0;
+	return rebuild_dfa(c);
+}
+
+// After an evaluation on the automaton: which entries of the global array the corpus really uses (the
+// host's sample saw 2 MB of it).  Where that is more than a few lookups in 100,000, LDS is laid out
+// again with those entries counted in (results never depend on it: only where a lookup is answered).
+constexpr uint32_t kDfaRelayouts = 2;
+constexpr uint32_t kDfaArrivalBlocks = 8; // workgroups of the histogram launch that bin the arrival stream (a few percent of the miss stream's entries at most)
+bool relayout_dfa(tokscore_ctx *c) {
+	(void)hipDeviceSynchronize();
+	const DfaImage &g = c->dimg;
+	const size_t n = g.nslots - g.hot_slots;
+	if (n == 0) return true;
+	std::vector<uint32_t> hits(n);
+	const DfaWork W = dfa_work(c);
+	if (hipMemcpy(hits.data(), W.cold_hit, n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
+	uint64_t total = 0;
+	for (uint32_t h : hits) total += h;
+	c->dfa_second_hits = total;
+	c->dfa_relayouts++;
+	if (total * 40000 < (c->total + c->D) * (uint64_t)c->dfa_evals) return true; // rare enough as it is
+	if (c->dfa_prior.size() != g.n_entries) c->dfa_prior.assign(g.n_entries, 0);
+	for (size_t i = 0; i < n; i++) {
+		if (!hits[i] || g.ent_of[i] == DfaImage::kEvNone) continue;
+		uint32_t &p = c->dfa_prior[g.ent_of[i]];
+		const uint64_t v = (uint64_t)p + (hits[i] + c->dfa_evals - 1) / c->dfa_evals;
+		p = (uint32_t)std::min<uint64_t>(v, 0xFFFFFFFFull);
+	}
+	return rebuild_dfa(c);
 }
 
 int ensure_out(tokscore_ctx *c) {
@@ -1023,8 +1076,8 @@ int fetch_out(tokscore_ctx *c, hipStream_t s) {
 	const uint64_t n = c->V + 5;
 	c->h_out[n] = 0;
 	HIP_TRY(c, hipMemcpyAsync(c->h_out, c->d_out, n * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-	if (c->scan_path >= 1 && c->d_cursor)
-		HIP_TRY(c, hipMemcpyAsync(c->h_out + n, c->d_cursor, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+	const uint32_t *cursor = c->dfa_used_last ? c->d_dcursor : (c->scan_path >= 1 ? c->d_cursor : nullptr);
+	if (cursor) HIP_TRY(c, hipMemcpyAsync(c->h_out + n, cursor, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
 	HIP_TRY(c, hipStreamSynchronize(s));
 	c->patch_in_flight = false;
 	return TOKSCORE_OK;
@@ -1053,7 +1106,14 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 				c->dfa_state = -1;
 			}
 		}
+	} else if (use_dfa && c->dfa_evals >= 1 && c->dfa_relayouts < kDfaRelayouts && c->dfa_relayout_on) {
+		if (!relayout_dfa(c)) {
+			free_dfa(c);
+			c->dfa_state = -1;
+			use_dfa = false;
+		}
 	}
+	if (use_dfa) c->dfa_evals++;
 	TrieDev T = trie_dev(c);
 	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
 	ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
@@ -1078,17 +1138,17 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	auto mark = [&](int k) -> hipError_t { return ev && (!scan_only || k == 1 || k == 2) ? hipEventRecord(ev[k], s) : hipSuccess; };
 	c->dfa_used_last = use_dfa;
 	if (use_dfa) {
-		// prepare (cursors), scan (clears and presets the output itself), fix-up, two histograms, cold counters
+		// scan (clears and presets the output itself), then fix-up + histograms, then the reduction
+		// (which also leaves the cursors ready for the next evaluation)
 		const StreamDev Qm{c->d_dstream_m, c->dstream_cap, c->d_dfill_m, c->d_dcursor};
 		const StreamDev Qa{c->d_dstream_a, c->dstream_cap, c->d_dfill_a, c->d_dcursor + 4};
 		const DfaDev A = dfa_dev(c);
 		const DfaWork W = dfa_work(c);
-		launch_dfa_prepare(nullptr, (uint32_t)c->V, c->D, c->total, Qm, Qa, c->dplan.blocks * c->dplan.waves_per_block, c->d_dcursor + 8, s);
 		launch_dfa_scan(A, W, Qm, Qa, c->dplan, s, OutInit{d_out, (uint32_t)c->V, c->D, c->total}, ev ? ev[1] : nullptr, ev ? ev[2] : nullptr);
-		launch_dfa_fixup(A, W, c->d_dcodes, c->d_dcursor + 8, ++c->dfa_epoch, d_out, (uint32_t)c->V + 3, s);
-		launch_histogram_events(Qm, A.hot_slots, c->d_dev_miss, c->d_dpool, d_out, (uint32_t)c->V + 3, c->d_dslab, c->dslab_blocks, s);
-		launch_histogram_events(Qa, A.hot_slots, c->d_dev_arr, c->d_dpool, d_out, (uint32_t)c->V + 3, c->d_dslab, c->dslab_blocks, s);
-		launch_dfa_cold_reduce(A, W, d_out, (uint32_t)c->V + 3, s);
+		// (the histogram's workgroups take a CU each, LDS full of bins: no more of them than CUs, both streams together)
+		const uint32_t arr_blocks = std::min<uint32_t>(kDfaArrivalBlocks, std::max<uint32_t>(1, c->dslab_blocks / 8));
+		launch_dfa_count(A, W, Qm, Qa, c->d_dcodes, c->d_dcursor + 8, ++c->dfa_epoch, d_out, (uint32_t)c->V + 3, c->d_dslab,
+		                 c->dslab_blocks - arr_blocks, arr_blocks, c->dplan.blocks * c->dplan.waves_per_block, s);
 	} else if (c->scan_path == 2) {
 		StreamDev Q{c->d_stream, c->stream_cap_batches, c->d_fill, c->d_cursor};
 		const uint32_t first_batches = c->d_tprep ? c->rplan.blocks * c->rplan.waves_per_block : 0u;
@@ -1200,7 +1260,7 @@ void build_index(tokscore_ctx *c) {
 }
 
 int check_overflow(tokscore_ctx *c) { // after fetch_out
-	if (c->scan_path < 1) return TOKSCORE_OK;
+	if (c->scan_path < 1 && !c->dfa_used_last) return TOKSCORE_OK;
 	if (c->h_out[c->V + 5] >> 32) return fail(c, TOKSCORE_E_CAPACITY, "token stream overflow (internal capacity bound violated)");
 	return TOKSCORE_OK;
 }
@@ -1443,6 +1503,7 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->dfa_max_slots = std::max<uint64_t>(1024, env_u64("TOKSCORE_DFA_SLOTS", 6u << 20));
 	c->dfa_chains = (uint32_t)env_u64("TOKSCORE_DFA_CHAINS", 0);
 	c->dfa_lds_cap = (uint32_t)env_u64("TOKSCORE_DFA_LDS", 0);
+	c->dfa_relayout_on = env_u64("TOKSCORE_DFA_RELAYOUT", 1) != 0;
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
@@ -1645,8 +1706,8 @@ int tokscore_async_status(tokscore_ctx *c, void *stream, int *overflowed) {
 	(void)hipSetDevice(c->device);
 	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
 	uint32_t words[2] = {0, 0};
-	if (c->plan_valid && c->scan_path >= 1 && c->d_cursor)
-		HIP_TRY(c, hipMemcpyAsync(words, c->d_cursor, sizeof words, hipMemcpyDeviceToHost, s));
+	const uint32_t *cursor = !c->plan_valid ? nullptr : (c->dfa_used_last ? c->d_dcursor : (c->scan_path >= 1 ? c->d_cursor : nullptr));
+	if (cursor) HIP_TRY(c, hipMemcpyAsync(words, cursor, sizeof words, hipMemcpyDeviceToHost, s));
 	HIP_TRY(c, hipStreamSynchronize(s));
 	*overflowed = words[1] != 0;
 	return TOKSCORE_OK;
@@ -2254,6 +2315,8 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 		info->dfa_hot_fraction = c->dimg.hot_fraction();
 		info->dfa_build_ms = c->dfa_build_ms;
 		info->dfa_plan_ms = c->dfa_plan_ms;
+		info->dfa_second_hits = c->dfa_second_hits;
+		info->dfa_relayouts = c->dfa_relayouts;
 		if (c->dfa_used_last) info->scan_path = 2;
 	}
 	return TOKSCORE_OK;
@@ -2330,7 +2393,20 @@ int tokscore_hostdfa_check(tokscore_ctx *c, const uint8_t *bytes, const uint64_t
 	std::string why;
 	if (!c->trie.BuildDfa(&img, opt, &why)) return fail(c, TOKSCORE_E_VOCAB, why);
 	uint64_t global_reads = 0;
-	DfaRun(img, bytes, off, D, c->V, counts, total_tokens, &global_reads);
+	std::vector<uint32_t> hits;
+	DfaRun(img, bytes, off, D, c->V, counts, total_tokens, &global_reads, &hits);
+	// TOKSCORE_HOSTDFA_RELAYOUT=n: what relayout_dfa does after an evaluation, n times -- the image built
+	// again with the first run's hits in the global array counted in; results and stats are the last run's
+	std::vector<uint32_t> prior;
+	for (uint64_t r = env_u64("TOKSCORE_HOSTDFA_RELAYOUT", 0); r > 0; r--) {
+		if (prior.size() != img.n_entries) prior.assign(img.n_entries, 0);
+		for (size_t i = 0; i < hits.size(); i++)
+			if (hits[i] && img.ent_of[i] != DfaImage::kEvNone) prior[img.ent_of[i]] += hits[i];
+		opt.prior = prior.data(), opt.prior_entries = (uint32_t)prior.size();
+		opt.corpus_bytes = off[D] - off[0] + D;
+		if (!c->trie.BuildDfa(&img, opt, &why)) return fail(c, TOKSCORE_E_VOCAB, why);
+		DfaRun(img, bytes, off, D, c->V, counts, total_tokens, &global_reads, &hits);
+	}
 	if (stats) {
 		stats[0] = img.nslots, stats[1] = img.real_slots, stats[2] = img.virtual_slots, stats[3] = img.ncodes;
 		stats[4] = img.hot_used, stats[5] = global_reads, stats[6] = img.sample_steps, stats[7] = img.sample_virtual;

@@ -12,12 +12,14 @@ for env in [{"TOKSCORE_DFA_CHAINS": c} for c in sys.argv[1:]]:
     s = ta.Scorer(0)
     s.set_vocab(*synth.pack_vocab(tokens))
     s.set_corpus(corpus, off)
-    s.score()
+    for _ in range(3):  # (the first evaluations also choose again what LDS holds)
+        s.score()
     ts = []
     for _ in range(8):
         s.score()
         ts.append(s.last_timing())
     ts = np.array(ts[2:])
     i = s.info()
-    print(env, os.environ.get("TOKSCORE_SAMPLE_MB"), "eval %.4f scan %.4f fix %.4f hist %.4f ms" % tuple(ts.mean(0)), "lds used", i.dfa_lds_used, "build %.1f ms" % i.dfa_build_ms, flush=True)
+    print(env, os.environ.get("TOKSCORE_SAMPLE_MB"), "eval %.4f scan %.4f fix %.4f hist %.4f ms" % tuple(ts.mean(0)), "lds used", i.dfa_lds_used, "build %.1f ms" % i.dfa_build_ms,
+          "relayouts", i.dfa_relayouts, "second hits", i.dfa_second_hits, flush=True)
     s.close()
