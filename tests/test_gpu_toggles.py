@@ -51,7 +51,7 @@ def test_deltas_equal_oracle_differences(env, monkeypatch):
         s.set_vocab(*synth.pack_vocab(tokens))
         s.set_corpus(corpus, off)
         base = s.score()
-        assert s.info().scan_path == (1 if env.get("TOKSCORE_SCAN") == "tile" else 2)
+        assert s.info().base_scan_path == (1 if env.get("TOKSCORE_SCAN") == "tile" else 2)
         enabled = np.ones(V, dtype=bool)
         rng = np.random.default_rng(7)
         multi = [i for i, t in enumerate(tokens) if len(t) >= 2]
