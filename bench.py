@@ -9,8 +9,11 @@ a ~100 MB wiki-like shard (seeded synthetic stand-in) with
 vocabulary per GPU; every rank scores its own shard (weak scaling, no data-path collective
 besides the count all-reduce).
 
-    python bench.py [--gpus N --steps K --warmup W] [--mb 100] [--vocab 32000]
+    python bench.py [--gpus N --steps K --warmup W] [--mb 100] [--vocab 32000] [--vocab-file tokens.json[.gz]] [--split]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`--split`: strong scaling -- ONE shard of --mb MB, its documents dealt out to the N ranks in contiguous
+blocks (what tests/test_sharding_gloo.py checks on CPU); "scaling": "strong" in the line.
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself -- a child
 `python -m torch.distributed.run`, before anything here touches the GPU -- and refuses loudly when
@@ -76,6 +79,54 @@ def cpu_baseline(corpus, off, tokens, sample_bytes=100_000_000):  # the whole be
                          % (d_end, nbytes, cores)}
     out["port_value"] = port
     return out, {"bytes": nbytes, "docs": d_end, "oracle": oracle_result, "reference": ref_result}
+
+
+def load_vocab_file(path):
+    """tokens.json[.gz] as the reference's TokenGenerator writes it (SolutionFile.cpp:27-41): {"tokens": [...]}"""
+    import gzip
+    op = gzip.open if path.endswith(".gz") else open
+    with op(path, "rt", encoding="utf-8") as f:
+        return [t.encode("utf-8") for t in json.load(f)["tokens"]]
+
+
+def split_shard(corpus, off, rank, world):
+    """--split: rank r's contiguous block of the shard's documents, blocks of (nearly) equal byte size -- the
+    partition tests/test_sharding_gloo.py checks (tokenizer_amd/shard.py)."""
+    from tokenizer_amd import shard
+    return shard.shard_corpus(corpus, off, rank, world)
+
+
+def settle(scorer, out_ptr, stream_ptr, sync):
+    """Before any timing: the evaluations in which the library still arranges itself -- the first one repairs
+    every range's entry state, and the automaton scan lays LDS out again from its own counters after the
+    first two (tokscore_info.dfa_relayouts).  -> milliseconds of each evaluation, host clock."""
+    ms = []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        scorer.score_async(out_ptr, stream_ptr)
+        sync()
+        ms.append((time.perf_counter() - t0) * 1e3)
+        i = scorer.info()
+        if len(ms) >= 2 and (not i.dfa_active or i.dfa_relayouts >= 2) and ms[-1] < 2 * min(ms):
+            break
+    return ms
+
+
+def after_toggle(scorer, tokens, out_ptr, stream_ptr, sync):
+    """What one toggle costs the next full evaluations (host clock, ms): the first ones run on the plan's own
+    scan, then the automaton's image is rebuilt from the vocabulary as it is."""
+    multi = [i for i, t in enumerate(tokens) if len(t) > 3]
+    scorer.toggle(int(multi[len(multi) // 2]), False)
+    ms, active = [], []
+    for _ in range(6):
+        t0 = time.perf_counter()
+        scorer.score_async(out_ptr, stream_ptr)
+        sync()
+        ms.append((time.perf_counter() - t0) * 1e3)
+        active.append(int(scorer.info().dfa_active))
+    scorer.toggle(int(multi[len(multi) // 2]), True)
+    settle(scorer, out_ptr, stream_ptr, sync)
+    return {"ms": ms, "automaton_scan": active, "note": "full evaluations after ONE toggle, host clock with a sync each"}
 
 
 def parity_check(gpu_vec, V, total_bytes, checked):
@@ -285,6 +336,54 @@ def two_in_flight(first, tokens, corpus, off, dev, steps):
         second.close()
 
 
+def annealed_vocab_block(dev, args, synth, ta):
+    """Not the headline: the same measurement with the vocabulary the REFERENCE's own annealer wrote
+    (tests/golden/wiki_annealed/tokens.json.gz: 30,275 tokens, 124,789 trie nodes, most prefixes not tokens) on
+    --mb MB of the kind of text it was annealed on (synth.wiki_like seed 1234, 20,000 words), checked against the
+    C restatement on the whole shard.  A vocabulary of that shape does not suit the automaton scan (tokscore.hip:
+    ensure_dfa); the plan's own scan serves it."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_ffi as O
+    path = os.path.join(ROOT, "tests", "golden", "wiki_annealed", "tokens.json.gz")
+    tokens = load_vocab_file(path)
+    corpus, off = synth.wiki_like(int(args.mb * 1e6), seed=1234, n_words=20_000)
+    V = len(tokens)
+    s = ta.Scorer(dev.index or 0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        out = torch.zeros(V + 5, dtype=torch.int64, device=dev)
+        stream = torch.cuda.current_stream()
+        settle(s, out.data_ptr(), stream.cuda_stream, torch.cuda.synchronize)
+        s.set_timing(1)
+        s.drain_timings()
+        n = max(3, args.steps // 2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            s.score_async(out.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        tm = np.array(s.drain_timings())
+        got = out.cpu().numpy().view(np.uint64)
+        info = s.info()
+        voc = O.OracleVocab(*synth.pack_vocab(tokens))
+        counts, tt, tb = voc.score(corpus, off, threads=min(16, os.cpu_count() or 1))
+        exact = bool(np.array_equal(got[:V + 3], counts)) and int(got[V + 3]) == int(tt) and int(got[V + 4]) == int(tb)
+        scan_ms = float(tm[:, 1].mean())
+        alg = int(info.corpus_bytes) + 8 * (V + 3)
+        return {"value": len(corpus) * n / dt / 1e9, "unit": "GB/s", "ms_per_step": dt / n * 1e3, "steps": n,
+                "vocab": V, "trie_nodes": int(info.trie_nodes), "bytes": int(info.corpus_bytes), "total_tokens": int(got[V + 3]),
+                "scan_path": "lds_automaton" if info.dfa_active else {1: "lds_tile", 2: "lds_stream"}.get(int(info.scan_path), "generic"),
+                "roofline": {"kernel_ms": scan_ms, "achieved": alg / (scan_ms * 1e-3) / 1e9, "frac": alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "eval_kernels_ms": float(tm[:, 0].mean())},
+                "parity_checked": {"against": "oracle", "bytes": int(info.corpus_bytes), "exact": exact},
+                "workload": "tests/golden/wiki_annealed/tokens.json.gz on wiki-like %.0f MB (seed 1234, 20,000 words)" % args.mb}
+    finally:
+        s.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -293,6 +392,10 @@ def main():
     ap.add_argument("--mb", type=float, default=100.0, help="shard size per GPU in MB")
     ap.add_argument("--vocab", type=int, default=32000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--vocab-file", default=None, help="tokens.json[.gz] of the reference's format instead of the built vocabulary")
+    ap.add_argument("--split", action="store_true", help="strong scaling: one --mb shard, its documents split over the ranks")
+    ap.add_argument("--seed", type=int, default=20201120)
+    ap.add_argument("--words", type=int, default=0, help="lexicon size of the synthetic text (0: synth.wiki_like's default)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("BENCH_REHEARSAL") != "1":
@@ -338,9 +441,17 @@ def main():
 
     # ---- synthetic shard (configs[1] stand-in) and a vocabulary shared by all ranks ----
     nbytes = int(args.mb * 1e6)
-    vocab_src, _ = synth.wiki_like(2_000_000, seed=20201120)
-    tokens = synth.build_vocab(vocab_src, args.vocab)
-    corpus, off = synth.wiki_like(nbytes, seed=20201120 + rank)
+    kw = {"n_words": args.words} if args.words else {}
+    if args.vocab_file:
+        tokens = load_vocab_file(args.vocab_file)
+    else:
+        vocab_src, _ = synth.wiki_like(2_000_000, seed=args.seed, **kw)
+        tokens = synth.build_vocab(vocab_src, args.vocab)
+    if args.split:  # one shard for the whole job, this rank's block of its documents
+        corpus, off = synth.wiki_like(nbytes, seed=args.seed, **kw)
+        corpus, off = split_shard(corpus, off, rank, world)
+    else:
+        corpus, off = synth.wiki_like(nbytes, seed=args.seed + rank, **kw)
     V = len(tokens)
 
     scorer = ta.Scorer(local_rank)  # raises when the HIP library or the GPU is missing
@@ -369,6 +480,10 @@ def main():
     # dispatch carries them itself; the other scan paths have a record before and after).  Marking
     # every launch, and every kernel of it, costs 8 % of a step (a record holds the stream for
     # 3 - 4 us; tools/dbg/ab_steps.py), which a caller without a profiler does not pay.
+    def sync():
+        torch.cuda.synchronize()
+
+    settle_ms = settle(scorer, out.data_ptr(), stream.cuda_stream, sync)
     sample_every = 4 if args.steps >= 8 else 1
     scorer.set_timing(2, sample_every)
     elapsed = timed_steps(step, fence, args.steps, args.warmup, after_warmup=scorer.drain_timings)
@@ -395,9 +510,27 @@ def main():
         torch.cuda.synchronize()
         local_vec = out.cpu().numpy().view(np.uint64).copy()
     info = scorer.info()
+    parity_ranks = None
+    if world > 1 and not args.no_cpu:
+        # configs[1]'s bit-exact count check at N > 1: every rank's own evaluation against the C restatement of the
+        # reference's path on the same shard (16 host threads per rank), the verdicts gathered with a MIN all-reduce
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_ffi as O
+        voc = O.OracleVocab(*synth.pack_vocab(tokens))
+        counts, tt, tb = voc.score(corpus, off, threads=min(16, os.cpu_count() or 1))
+        mine = bool(np.array_equal(local_vec[:V + 3], counts)) and int(local_vec[V + 3]) == int(tt) and int(local_vec[V + 4]) == int(tb)
+        flag = torch.tensor([1 if mine else 0], dtype=torch.int64, device="cpu" if rehearsal else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        parity_ranks = {"against": "oracle", "ranks": world, "exact": bool(int(flag.item()) == 1),
+                        "note": "every rank's own shard against oracle/tokscore_oracle.c; MIN over ranks"}
     if rank == 0:
         value = total_bytes_all * args.steps / elapsed / 1e9
         alg_bytes = int(info.corpus_bytes) + 8 * (V + 3)
+        if info.dfa_active:
+            scan_kernel, scan_name = "dfa_scan_asm_kernel<%d>" % info.dfa_chains, "lds_automaton"
+        else:
+            scan_kernel = {1: "scan_tile_kernel", 2: "scan_ranges_kernel"}.get(int(info.scan_path), "scan_generic_kernel")
+            scan_name = {1: "lds_tile", 2: "lds_stream"}.get(int(info.scan_path), "generic")
         scan_avg_ms = float(np.mean(scan_ms))
         achieved = alg_bytes / (scan_avg_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(int(info.corpus_bytes))
@@ -408,17 +541,23 @@ def main():
         rec = {
             "metric": "corpus GB/s scored per full-vocab eval",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.split else "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic" + (" (REHEARSAL: ranks share GPU 0, gloo)" if rehearsal else "")
             + (" (RCCL SELFTEST: one rank, the all-reduce of the N > 1 path inside every step)" if selftest else ""),
-            "config": {"workload": "configs[1]: wiki-like %.0f MB shard per GPU (seed 20201120+rank), "
-                                   "one full-vocabulary scoring pass, V=%d" % (args.mb, V),
+            "config": {"workload": ("configs[1]: ONE wiki-like %.0f MB shard (seed %d) split by documents over the ranks, "
+                                    "one full-vocabulary scoring pass, V=%d" if args.split else
+                                    "configs[1]: wiki-like %.0f MB shard per GPU (seed %d+rank), "
+                                    "one full-vocabulary scoring pass, V=%d") % (args.mb, args.seed, V)
+                                   + (", vocabulary from %s" % os.path.basename(args.vocab_file) if args.vocab_file else ""),
                        "docs_per_gpu": int(info.corpus_docs), "bytes_per_gpu": int(info.corpus_bytes),
                        "vocab": V, "max_token_bytes": int(info.max_len), "trie_slots": int(info.trie_slots),
                        "trie_lds_slots": int(info.trie_lds_slots), "chunks": int(info.chunks),
-                       "scan_path": {1: "lds_tile", 2: "lds_stream"}.get(int(info.scan_path), "generic"),
+                       "scan_path": scan_name,
+                       "automaton": {"slots": int(info.dfa_slots), "virtual_slots": int(info.dfa_virtual_slots), "lds_slots": int(info.dfa_lds_slots),
+                                     "lds_used": int(info.dfa_lds_used), "chains": int(info.dfa_chains), "relayouts": int(info.dfa_relayouts),
+                                     "lookups_answered_by_L2_per_evaluation": int(info.dfa_second_hits)} if info.dfa_active else None,
                        "parallelism": "documents sharded over %d GPU(s), 1 count all-reduce" % world},
-            "roofline": {"bound": "hbm", "kernel": {1: "scan_tile_kernel", 2: "scan_ranges_kernel"}.get(int(info.scan_path), "scan_generic_kernel"),
+            "roofline": {"bound": "hbm", "kernel": scan_kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src, "alg_bytes_per_launch": alg_bytes, "kernel_ms": scan_avg_ms,
                          "kernel_ms_from": "HIP events attached to the kernel's dispatch (hipExtLaunchKernel: its own begin and end) on %d of the %d timed launches (every %s)"
@@ -428,12 +567,21 @@ def main():
                          "measured_stream_read_GBps": {"hbm_4GiB": stream_hbm, "shard_sized_buffer": stream_shard},
                          "frac_of_measured_hbm_stream": achieved / stream_hbm if stream_hbm else None},
             "total_tokens": int(host[V + 3]), "h2d_inclusive_GBps": info.corpus_bytes / (h2d_s + elapsed / args.steps) / 1e9,
+            # once per corpus and vocabulary, outside the timed region: the plan (tokscore_set_corpus: upload, chunking,
+            # stream image), the automaton's image and buffers, and the evaluations that still arrange things
+            "plan_ms": {"set_corpus_host_ms": h2d_s * 1e3, "automaton_plan_ms": float(info.dfa_plan_ms), "automaton_image_build_ms": float(info.dfa_build_ms)},
+            "first_evaluation_ms": settle_ms[0], "settling_evaluations_ms": settle_ms,
         }
         if world == 1 and not args.no_cpu:
             rec["two_evaluations_in_flight"] = two_in_flight(scorer, tokens, corpus, off, dev, args.steps)
             rec["cpu_baseline"], checked = cpu_baseline(corpus, off, tokens)
             rec["parity_checked"] = parity_check(local_vec, V, int(info.corpus_bytes), checked)
+            rec["eval_after_toggle_ms"] = after_toggle(scorer, tokens, out.data_ptr(), stream.cuda_stream, sync)
             rec["annealing_moves_per_s"] = moves_per_sec(scorer, tokens, corpus, off)
+            if not args.vocab_file:
+                rec["headline_annealed_vocab"] = annealed_vocab_block(dev, args, synth, ta)
+        if parity_ranks is not None:
+            rec["parity_checked"] = parity_ranks
         print(json.dumps(rec))
         if rec.get("parity_checked", {}).get("exact") is False:
             sys.stderr.write("bench.py: the GPU result differs from the CPU %s on the bench shard\n" % rec["parity_checked"]["against"])

@@ -163,7 +163,9 @@ int tokscore_count_occurrences(tokscore_ctx *ctx, uint32_t max_cp, uint64_t *cou
  *   - TOKSCORE_E_CAPACITY when 8 bytes per KiB of corpus plus one row (4 * (V + 4) bytes) exceed
  *     the 16 MiB; fewer rows than tokscore_count_occurrences would take only make it slower.
  *   - TOKSCORE_E_STATE until the context has run one evaluation (tokscore_count_occurrences or
- *     tokscore_score*): copying the trie to the device is set-up and allocates.
+ *     tokscore_score*): copying the trie to the device is set-up and allocates.  Also while toggles
+ *     are pending (tokscore_toggle since the last evaluation): the next evaluation brings them to the
+ *     device, this call changes nothing of the context's state.
  *   - Every call on a GPU, from any context, shares that GPU's array: two calls that overlap on
  *     one GPU (two streams, two contexts, two threads) race.  Calls on one stream are ordered. */
 int tokscore_count_occurrences_static(tokscore_ctx *ctx, uint32_t max_cp, void *d_out, void *stream);

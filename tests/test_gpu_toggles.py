@@ -182,3 +182,69 @@ def test_annealing_like_sequence_takes_token_starts_from_the_ranges():
             total = now
     finally:
         s.close()
+
+
+def test_range_exit_tags_survive_the_wrap_of_their_16_bit_epoch(monkeypatch):
+    """The ranges scan tags a repaired range exit with a 16-bit evaluation number (kernels_stream.hip:
+    exit_now); when the numbers go round, the words are cleared so that a repair of exactly one cycle ago
+    cannot pass for this evaluation's.  Toggles before every evaluation make the ordered fix-up pass run."""
+    monkeypatch.setenv("TOKSCORE_SCAN", "stream")
+    monkeypatch.setenv("TOKSCORE_DFA", "0")
+    monkeypatch.setenv("TOKSCORE_FIX_EPOCH_START", "65530")
+    corpus, off = synth.wiki_like(1_200_000, seed=33)
+    tokens = synth.build_vocab(corpus[:400_000], 4000)
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        rng = np.random.default_rng(3)
+        multi = [i for i, t in enumerate(tokens) if len(t) > 1]
+        on = np.ones(len(tokens), dtype=bool)
+        for it in range(12):
+            for i in rng.choice(multi, size=6, replace=False):
+                on[i] = not on[i]
+                s.toggle(int(i), bool(on[i]))
+            got = s.score()
+            assert s.info().base_scan_path == 2
+            kept = [t if on[i] else b"" for i, t in enumerate(tokens)]
+            want = O.OracleVocab(*synth.pack_vocab(kept)).score(corpus, off, threads=8)
+            assert got[1:] == want[1:] and np.array_equal(got[0], want[0]), it
+    finally:
+        s.close()
+
+
+@pytest.mark.parametrize("incr_div", [None, "3"])
+def test_incremental_parity_under_the_default_cost_model_and_under_the_test_rule(monkeypatch, incr_div):
+    """The same toggle / incremental re-score sequence with TOKSCORE_INCR_DIV unset (what users get: the cost
+    model of tokscore_score_incremental decides between two partial passes and a full evaluation) and with the
+    test suite's plain rule; a corpus large enough that the model has a choice.  Which way it went is in
+    tokscore_info.rescored_chunks; the counts are the oracle's either way."""
+    if incr_div is None:
+        monkeypatch.delenv("TOKSCORE_INCR_DIV", raising=False)
+    else:
+        monkeypatch.setenv("TOKSCORE_INCR_DIV", incr_div)
+    monkeypatch.setenv("TOKSCORE_SCAN", "tile")
+    monkeypatch.setenv("TOKSCORE_DFA", "0")
+    corpus, off = synth.wiki_like(24_000_000, seed=41)
+    tokens = synth.build_vocab(corpus[:1_000_000], 8000)
+    tokens.append(bytes(corpus[12_345_600:12_345_613]).lower())   # occurs in very few chunks
+    V = len(tokens)
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        s.score()
+        enabled = np.ones(V, dtype=bool)
+        took_partial = []
+        for i in (V - 1, V // 2, V - 1):
+            enabled[i] = not enabled[i]
+            s.toggle(int(i), bool(enabled[i]))
+            got = s.score(incremental=True)
+            kept = [t if enabled[k] else b"" for k, t in enumerate(tokens)]
+            want = O.OracleVocab(*synth.pack_vocab(kept)).score(corpus, off, threads=8)
+            assert got[1:] == want[1:] and np.array_equal(got[0], want[0])
+            took_partial.append(s.info().rescored_chunks != 0xFFFFFFFF)
+        if incr_div == "3":
+            assert took_partial[0] and took_partial[2], "a token in a handful of chunks: the partial passes were expected"
+    finally:
+        s.close()

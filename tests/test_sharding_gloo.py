@@ -31,9 +31,11 @@ def _worker(rank, world, port, tokens, corpus, off, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    c, o = shard.shard_corpus(corpus, off, rank, world)
+    import bench  # the step, the reduction, the timing loop and --split's partition are bench.py's own code, not a copy of it
+    c, o = bench.split_shard(corpus, off, rank, world)
+    c2, o2 = shard.shard_corpus(corpus, off, rank, world)
+    assert np.array_equal(c, c2) and np.array_equal(o, o2)
     voc = O.OracleVocab(*synth.pack_vocab(tokens))
-    import bench  # the step, the reduction and the timing loop are bench.py's own code, not a copy of it
     t = torch.zeros(len(tokens) + 5, dtype=torch.int64)
     calls = []
 

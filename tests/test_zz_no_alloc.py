@@ -102,3 +102,39 @@ def test_static_with_few_rows_and_refusal(monkeypatch):
     finally:
         s.close()
         hip.free(d_out)
+
+
+def test_static_call_leaves_pending_toggles_to_the_next_evaluation():
+    """score -> toggle -> count_occurrences_static -> score(incremental): the static call must not swallow the
+    pending toggle (it refuses while one is pending: it never changes the context's state), and the
+    incremental re-score that follows equals a full evaluation of the toggled vocabulary."""
+    hip = _Hip()
+    max_cp = 6
+    corpus, off = synth.wiki_like(1_500_000, seed=27)
+    tokens = synth.build_vocab(corpus[:400_000], 5000)
+    V = len(tokens)
+    s = ta.Scorer(0)
+    d_out = hip.malloc((V + 4) * 8)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        s.score()
+        multi = [i for i, t in enumerate(tokens) if len(t) > 2]
+        s.toggle(multi[7], False)
+        with pytest.raises(ta.TokscoreError) as ei:
+            s.count_occurrences_static(max_cp, d_out.value)
+        assert ei.value.status == E_STATE and "pending" in str(ei.value)
+        got = s.score(incremental=True)
+        kept = [b"" if i == multi[7] else t for i, t in enumerate(tokens)]
+        want = O.OracleVocab(*synth.pack_vocab(kept)).score(corpus, off, threads=8)
+        assert got[1:] == want[1:] and np.array_equal(got[0], want[0])
+        # with nothing pending the static call runs, and counts the vocabulary as it now is
+        exp_counts, exp_pos = s.count_occurrences(max_cp)
+        s.count_occurrences_static(max_cp, d_out.value)
+        host = hip.to_host(d_out, V + 4)
+        assert np.array_equal(host[:V + 3], exp_counts) and int(host[V + 3]) == exp_pos
+        full = s.score()
+        assert full[1:] == want[1:] and np.array_equal(full[0], want[0])
+    finally:
+        s.close()
+        hip.free(d_out)

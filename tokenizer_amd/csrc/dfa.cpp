@@ -66,6 +66,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	// without a root child (the separator, "other", bytes that only occur inside tokens) ----
 	const uint32_t ROOT = 0;
 	const uint32_t S = N + ncodes; // state ids: [1, N) nodes, N + c stand-in of code c
+	if (S >= (1u << 24)) return fail("too many trie nodes (entry keys hold a state in 24 bits)");
 	std::vector<uint32_t> par(N, 0);
 	std::vector<uint8_t> pbyte(N, 0), reach(N, 0);
 	reach[0] = 1;
@@ -247,21 +248,26 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	const bool sampled = out->sample_steps != 0;
 	// what an earlier image counted on the whole corpus: uses of entries LDS did not hold.  The sample's
 	// counts are brought to the corpus's scale first, so that the two can be compared.
-	if (opt.prior && opt.prior_entries == ent.size()) {
+	const bool have_prior = opt.prior_keys && opt.prior_counts && opt.prior_n != 0;
+	if (have_prior) {
 		if (sampled && opt.corpus_bytes > opt.sample_bytes) {
 			const uint64_t scale = opt.corpus_bytes / opt.sample_bytes;
 			for (auto &w : w_row) w *= scale;
 			for (auto &w : w_ent) w *= scale;
 		}
-		for (uint32_t s = 1; s < S; s++)
-			for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) {
-				if (!opt.prior[j]) continue;
-				w_ent[j] += opt.prior[j];
-				w_row[s] += opt.prior[j];
-				w_row[ent[j].target] += opt.prior[j];
+		size_t k = 0; // (entries are in key order: rows by state, a row's entries by code)
+		for (uint32_t s = 1; s < S && k < opt.prior_n; s++)
+			for (uint64_t j = row_off[s]; j < row_off[s + 1] && k < opt.prior_n; j++) {
+				const uint32_t key = s << 8 | ent[j].code;
+				while (k < opt.prior_n && opt.prior_keys[k] < key) k++;
+				if (k == opt.prior_n || opt.prior_keys[k] != key) continue;
+				const uint32_t n = opt.prior_counts[k];
+				w_ent[j] += n;
+				w_row[s] += n;
+				w_row[ent[j].target] += n;
 			}
 	}
-	const bool weighted = sampled || (opt.prior && opt.prior_entries == ent.size());
+	const bool weighted = sampled || have_prior;
 	// ---- which entries and rows are worth LDS ----
 	// The global array holds the whole automaton: every row complete, beyond hot_cap.  The LDS array
 	// is an overlay for the rows in use, the rows with the most lookups per LDS entry first, for as
@@ -554,14 +560,13 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	out->nslots = (uint32_t)nslots;
 	out->hot_slots = hot_cap;
 	out->cold_base = cold_base;
-	out->n_entries = (uint32_t)ent.size();
 	out->hot.assign(hot_cap, DfaImage::kEmptyWord);
 	out->slot.assign(2 * nslots, 0);
 	for (uint64_t i = 0; i < nslots; i++) out->slot[2 * i] = DfaImage::kEmptyWord;
 	out->gof.assign(hot_cap, 0);
 	out->ev_miss.assign(nslots, DfaImage::kEvNone);
 	out->ev_arr.assign(nslots, DfaImage::kEvNone);
-	out->ent_of.assign(nslots - hot_cap, DfaImage::kEvNone);
+	out->ent_key.assign(nslots - hot_cap, DfaImage::kEvNone);
 	out->real_slots = out->virtual_slots = out->hot_used = 0;
 	// the word of a state: where its next byte is looked up
 	auto state_word = [&](uint32_t s) -> uint32_t { return base_h[s] | (partial_row[s] ? DfaImage::kPartial : 0u); };
@@ -602,13 +607,13 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 				out->slot[2 * (uint64_t)t] = word;
 				out->slot[2 * (uint64_t)t + 1] = base_g[e.target];
 				out->ev_arr[t] = e.arr;
-				out->ent_of[t - hot_cap] = (uint32_t)j;
+				out->ent_key[t - hot_cap] = s << 8 | e.code;
 			}
 			if (e.virt) out->virtual_slots++;
 			else out->real_slots++;
 		}
 	}
-	out->sample_cold = sampled && !(opt.prior && opt.prior_entries == ent.size()) ? cold_steps : 0;
+	out->sample_cold = sampled && !have_prior ? cold_steps : 0;
 	out->max_events = max_events;
 	out->valid = true;
 	if (getenv("TOKSCORE_TRACE_HOST"))
@@ -618,7 +623,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 		        (double)out->sample_virtual / std::max<uint64_t>(1, out->sample_steps),
 		        (double)out->sample_miss / std::max<uint64_t>(1, out->sample_steps),
 		        (double)cold_steps / (double)std::max<uint64_t>(1, std::accumulate(w_row.begin(), w_row.end(), (uint64_t)0)),
-		        opt.prior ? " (with an earlier image's counts)" : "");
+		        have_prior ? " (with an earlier image's counts)" : "");
 	return true;
 }
 

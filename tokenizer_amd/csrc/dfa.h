@@ -71,11 +71,10 @@ struct DfaImage {
 	std::vector<uint32_t> gof;     // [hot_slots] by LDS base: the state's global base (0: its row is complete in LDS, or it has none)
 	std::vector<uint32_t> ev_miss; // [nslots] by state key: what leaving the state by a miss emits
 	std::vector<uint32_t> ev_arr;  // [nslots] by entry index: what arriving on a virtual entry emits
-	std::vector<uint32_t> ent_of;  // [nslots - hot_slots] host only: global entry -> the builder's entry number (kEvNone: none)
+	std::vector<uint32_t> ent_key; // [nslots - hot_slots] host only: global entry -> trie node of its row << 8 | code (kEvNone: no entry)
 	uint32_t hot_slots = 0;        // = DfaOptions::lds_slots
 	uint32_t cold_base = 0;
 	uint32_t hot_used = 0;         // entries in `hot`
-	uint32_t n_entries = 0;        // the builder's entries (DfaOptions::prior's length)
 	uint64_t sample_cold = 0;      // sample lookups that needed `slot`
 	std::vector<uint32_t> pool;
 	uint8_t code[256] = {};
@@ -102,10 +101,11 @@ struct DfaOptions {
 	const uint8_t *sample = nullptr; // raw corpus bytes for the choice of what LDS holds (lower-cased here)
 	uint64_t sample_bytes = 0;
 	uint64_t corpus_bytes = 0;     // what the sample stands for (scales its counts against `prior`)
-	// uses of the builder's entries an earlier image of the SAME vocabulary counted on the whole corpus
-	// (the scan's counters of the global array, through DfaImage::ent_of), or null
-	const uint32_t *prior = nullptr;
-	uint32_t prior_entries = 0;
+	// uses of entries that an earlier image counted on the whole corpus (the scan's counters of the global
+	// array, through DfaImage::ent_key): keys ascending, or null.  Keys name trie nodes, which toggles do
+	// not renumber, so the counts stay useful for the images built after toggles.
+	const uint32_t *prior_keys = nullptr, *prior_counts = nullptr;
+	size_t prior_n = 0;
 };
 
 // Host-side check of an image (CPU tests of the builder; never used by a scoring entry point): runs

@@ -739,7 +739,7 @@ bool plan_dfa_scan(uint32_t hot_slots, uint64_t prep_total, uint32_t num_cus, ui
 	plan->lds_bytes = ((plan->lds_slots + 3) & ~3u) * 4;
 	plan->blocks = num_cus;
 	plan->waves_per_block = 16;
-	plan->chains = chains_hint == 1 || chains_hint == 2 ? chains_hint : 4;
+	plan->chains = chains_hint == 1 || chains_hint == 4 ? chains_hint : 2; // (measured at 100 MB: 0.0613 / 0.0611 / 0.0666 ms for 1 / 2 / 4)
 	const uint64_t total_waves = (uint64_t)plan->blocks * plan->waves_per_block;
 	const uint64_t per_block = 64ull * plan->chains;
 	uint64_t rb = (prep_total + total_waves * per_block - 1) / (total_waves * per_block);

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -222,6 +223,7 @@ struct tokscore_ctx {
 	uint32_t nranges = 0;
 	uint32_t *d_range_state = nullptr; // entry | exit_a | exit_b, nranges words each
 	uint32_t fix_epoch = 0;          // tag of this evaluation's exit_b entries
+	bool fix_epoch_wrapped = false;  // (set after the first evaluation: tag 1 after that means the tags have gone round)
 	uint8_t *d_tprep = nullptr;      // the ranges transposed, 64 to a block (kernels_stream.hip: scan_ranges_kernel)
 	uint32_t halo = 0;
 	StreamScanPlan rplan = {};       // launch of scan_ranges_kernel
@@ -259,7 +261,8 @@ struct tokscore_ctx {
 	uint32_t dfa_epoch = 0;
 	bool dfa_used_last = false;    // the last full evaluation ran on the automaton scan
 	// what LDS holds is chosen again after a plan's first evaluations, from the scan's own counters
-	std::vector<uint32_t> dfa_prior; // uses of the builder's entries that LDS did not hold (DfaOptions::prior)
+	std::map<uint32_t, uint32_t> dfa_prior; // uses of entries that LDS did not hold, by DfaImage::ent_key (DfaOptions::prior_*)
+	std::vector<uint32_t> dfa_prior_keys, dfa_prior_counts; // ... flattened for the builder
 	uint32_t dfa_evals = 0;          // evaluations on the image as it is
 	uint32_t dfa_relayouts = 0;      // images built from counters (at most kDfaRelayouts per vocabulary state)
 	uint64_t dfa_second_hits = 0;    // lookups the global array answered with a hit, in the evaluations counted last
@@ -865,7 +868,9 @@ bool upload_dfa_image(tokscore_ctx *c) {
 	opt.sample = c->sample.empty() ? nullptr : c->sample.data();
 	opt.sample_bytes = c->sample.size();
 	opt.corpus_bytes = c->total + c->D;
-	if (!c->dfa_prior.empty()) opt.prior = c->dfa_prior.data(), opt.prior_entries = (uint32_t)c->dfa_prior.size();
+	c->dfa_prior_keys.clear(), c->dfa_prior_counts.clear();
+	for (const auto &kv : c->dfa_prior) c->dfa_prior_keys.push_back(kv.first), c->dfa_prior_counts.push_back(kv.second);
+	if (!c->dfa_prior.empty()) opt.prior_keys = c->dfa_prior_keys.data(), opt.prior_counts = c->dfa_prior_counts.data(), opt.prior_n = c->dfa_prior.size();
 	std::string why;
 	const auto t0 = std::chrono::steady_clock::now();
 	if (!c->trie.BuildDfa(&c->dimg, opt, &why)) return false;
@@ -1027,18 +1032,15 @@ bool rebuild_dfa(tokscore_ctx *c) {
 	return true;
 }
 
-// After toggles: the counters of the old vocabulary's entries say nothing about the new one's.
-bool refresh_dfa(tokscore_ctx *c) {
-	c->dfa_prior.clear();
-	c->dfa_relayouts = 0;
-	return rebuild_dfa(c);
-}
+// After toggles: the counts of the entries LDS did not hold stay (they are keyed by trie node and code, which a
+// toggle does not renumber), so the new image starts from what the corpus is known to use.
+bool refresh_dfa(tokscore_ctx *c) { return rebuild_dfa(c); }
 
 // After an evaluation on the automaton: which entries of the global array the corpus really uses (the
 // host's sample saw 2 MB of it).  Where that is more than a few lookups in 100,000, LDS is laid out
 // again with those entries counted in (results never depend on it: only where a lookup is answered).
 constexpr uint32_t kDfaRelayouts = 2;
-constexpr uint32_t kDfaArrivalBlocks = 8; // workgroups of the histogram launch that bin the arrival stream (a few percent of the miss stream's entries at most)
+constexpr uint32_t kDfaArrivalBlocks = 16; // workgroups of the histogram launch that bin the arrival stream (a few percent of the miss stream's entries at most)
 bool relayout_dfa(tokscore_ctx *c) {
 	(void)hipDeviceSynchronize();
 	const DfaImage &g = c->dimg;
@@ -1055,10 +1057,9 @@ bool relayout_dfa(tokscore_ctx *c) {
 	c->dfa_second_hits = total;
 	c->dfa_relayouts++;
 	if (total * 40000 < (c->total + c->D) * (uint64_t)c->dfa_evals) return true; // rare enough as it is
-	if (c->dfa_prior.size() != g.n_entries) c->dfa_prior.assign(g.n_entries, 0);
 	for (size_t i = 0; i < n; i++) {
-		if (!hits[i] || g.ent_of[i] == DfaImage::kEvNone) continue;
-		uint32_t &p = c->dfa_prior[g.ent_of[i]];
+		if (!hits[i] || g.ent_key[i] == DfaImage::kEvNone) continue;
+		uint32_t &p = c->dfa_prior[g.ent_key[i]];
 		const uint64_t v = (uint64_t)p + (hits[i] + c->dfa_evals - 1) / c->dfa_evals;
 		p = (uint32_t)std::min<uint64_t>(v, 0xFFFFFFFFull);
 	}
@@ -1159,7 +1160,7 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		const DfaWork W = dfa_work(c);
 		launch_dfa_scan(A, W, Qm, Qa, c->dplan, s, OutInit{d_out, (uint32_t)c->V, c->D, c->total}, ev ? ev[1] : nullptr, ev ? ev[2] : nullptr);
 		// (the histogram's workgroups take a CU each, LDS full of bins: no more of them than CUs, both streams together)
-		const uint32_t arr_blocks = std::min<uint32_t>(kDfaArrivalBlocks, std::max<uint32_t>(1, c->dslab_blocks / 8));
+		const uint32_t arr_blocks = std::min<uint32_t>(kDfaArrivalBlocks, std::max<uint32_t>(1, c->dslab_blocks / 16));
 		launch_dfa_count(A, W, Qm, Qa, c->d_dcodes, c->d_dcursor + 8, ++c->dfa_epoch, d_out, (uint32_t)c->V + 3, c->d_dslab,
 		                 c->dslab_blocks - arr_blocks, arr_blocks, c->dplan.blocks * c->dplan.waves_per_block, s);
 	} else if (c->scan_path == 2) {
@@ -1181,6 +1182,12 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		}
 		// ranges whose entry was not the previous range's exit (none while the vocabulary stays as it is)
 		c->fix_epoch = c->fix_epoch % 65535u + 1u;
+		if (c->fix_epoch == 1u && c->fix_epoch_wrapped && c->d_range_state && c->nranges) {
+			// the 16-bit tag starts over: an exit_b word written exactly one cycle ago would carry the current tag
+			// again.  Cleared here, before the fix-up that reads them (the scan does not touch exit_b).
+			HIP_TRY(c, hipMemsetAsync(c->d_range_state + 2 * (size_t)c->nranges, 0, (size_t)c->nranges * sizeof(uint32_t), s));
+		}
+		c->fix_epoch_wrapped = true;
 		launch_fixup_and_histogram_slots(stream_trie_dev(c), W, c->d_range_state + 2 * (size_t)c->nranges, c->d_cursor + 2, c->fix_epoch, Q,
 		                                 (uint32_t)c->simg.lt.size(), c->d_slot_id, d_out, (uint32_t)c->V + 3, c->d_slab, c->slab_blocks, s,
 		                                 first_batches);
@@ -1274,7 +1281,10 @@ void build_index(tokscore_ctx *c) {
 
 int check_overflow(tokscore_ctx *c) { // after fetch_out
 	if (c->scan_path < 1 && !c->dfa_used_last) return TOKSCORE_OK;
-	if (c->h_out[c->V + 5] >> 32) return fail(c, TOKSCORE_E_CAPACITY, "token stream overflow (internal capacity bound violated)");
+	if (c->h_out[c->V + 5] >> 32) {
+		c->stream_ready = 0; // the word is cleared by the prepare launch, which a "ready" stream skips: not sticky
+		return fail(c, TOKSCORE_E_CAPACITY, "token stream overflow (internal capacity bound violated)");
+	}
 	return TOKSCORE_OK;
 }
 
@@ -1517,6 +1527,8 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->dfa_chains = (uint32_t)env_u64("TOKSCORE_DFA_CHAINS", 0);
 	c->dfa_lds_cap = (uint32_t)env_u64("TOKSCORE_DFA_LDS", 0);
 	c->dfa_relayout_on = env_u64("TOKSCORE_DFA_RELAYOUT", 1) != 0;
+	c->fix_epoch = (uint32_t)(env_u64("TOKSCORE_FIX_EPOCH_START", 0) % 65536u); // (tests: start next to the 16-bit tag's wrap)
+	c->fix_epoch_wrapped = c->fix_epoch != 0;
 	c->dfa_max_cold_ppm = env_u64("TOKSCORE_DFA_MAX_COLD_PPM", c->dfa_max_cold_ppm);
 	c->dfa_max_virtual_ppm = env_u64("TOKSCORE_DFA_MAX_VIRTUAL_PPM", c->dfa_max_virtual_ppm);
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
@@ -1725,6 +1737,13 @@ int tokscore_async_status(tokscore_ctx *c, void *stream, int *overflowed) {
 	if (cursor) HIP_TRY(c, hipMemcpyAsync(words, cursor, sizeof words, hipMemcpyDeviceToHost, s));
 	HIP_TRY(c, hipStreamSynchronize(s));
 	*overflowed = words[1] != 0;
+	if (words[1] != 0) { // reported once: the next evaluation starts from a prepared stream (or, the automaton's, from the plan's scan)
+		c->stream_ready = 0;
+		if (c->dfa_used_last) {
+			free_dfa(c);
+			c->dfa_state = -1;
+		}
+	}
 	return TOKSCORE_OK;
 }
 
@@ -1843,6 +1862,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 					if (!seen) spec[nspec++] = ToggleSpec{c->pending[k].first, (uint32_t)r, 0u, c->row_chunks[r]};
 				}
 				int st = upload_toggle_batch(c, spec, nspec, true, s, &by_stream);
+				if (st == TOKSCORE_E_CAPACITY) return tokscore_score(c, counts, total_tokens, total_bytes); // too many streams for one launch: the full evaluation
 				if (st) return st;
 				StreamWork Wf = stream_work(c, false);
 				launch_find_toggle_streams(by_stream.B, Wf, (uint32_t)by_stream.pairs, c->nchunks, s);
@@ -2021,7 +2041,8 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		HIP_TRY(c, hipGetLastError());
 		c->stream_tokens_epoch = c->trie_epoch;
 	}
-	const uint64_t budget = c->knob_toggle_items;
+	// (one launch addresses at most 2^32 - 16 (pair, stream) items: a batch never asks for more than that)
+	const uint64_t budget = std::max<uint64_t>(1, std::min<uint64_t>(c->knob_toggle_items, 0xFFFFFFF0ull / std::max<uint64_t>(1, c->widest_chunk) / 2));
 	const StreamWork W0 = stream_work(c, false);
 	size_t first = 0;
 	while (first < moves.size()) {
@@ -2033,6 +2054,8 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		ToggleUpload up;
 		const double t_up0 = now();
 		st = upload_toggle_batch(c, moves.data() + first, n, false, s, &up, c->tg_list_hint);
+		if (st == TOKSCORE_E_CAPACITY) // a single move whose token occurs in more streams than one launch addresses: move by move, as the header promises
+			return score_toggles_one_by_one(c, token_index, enable, K, delta_total_tokens);
 		if (st) return st;
 		const double t_up1 = now();
 		up.B.starts = c->d_tok_starts;
@@ -2143,8 +2166,14 @@ int tokscore_count_occurrences_static(tokscore_ctx *c, uint32_t max_cp, void *d_
 		            "the trie is not in device memory yet: run tokscore_count_occurrences or tokscore_score once "
 		            "before the first tokscore_count_occurrences_static");
 	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-	int st = apply_pending(c, s); // copies into existing slots only
-	if (st) return st;
+	// Toggles since the last evaluation are patched into the device trie by the next evaluation, on the context's
+	// stream, from staging memory that evaluation owns.  This call must not do that on the caller's stream (not
+	// ordered against the context's, a pageable copy that cannot be captured) nor behind the back of an
+	// incremental re-score, which would find nothing pending and return the counts of before the toggle.
+	if (!c->pending.empty() || !c->pending_s.empty())
+		return fail(c, TOKSCORE_E_STATE,
+		            "toggles are pending: run an evaluation (tokscore_score* or tokscore_count_occurrences) before "
+		            "tokscore_count_occurrences_static, which never changes the context's state");
 	const uint32_t n_ids = (uint32_t)c->V + 3;
 	TrieDev T = trie_dev(c);
 	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
@@ -2412,12 +2441,14 @@ int tokscore_hostdfa_check(tokscore_ctx *c, const uint8_t *bytes, const uint64_t
 	DfaRun(img, bytes, off, D, c->V, counts, total_tokens, &global_reads, &hits);
 	// TOKSCORE_HOSTDFA_RELAYOUT=n: what relayout_dfa does after an evaluation, n times -- the image built
 	// again with the first run's hits in the global array counted in; results and stats are the last run's
-	std::vector<uint32_t> prior;
+	std::map<uint32_t, uint32_t> prior;
+	std::vector<uint32_t> pk, pc;
 	for (uint64_t r = env_u64("TOKSCORE_HOSTDFA_RELAYOUT", 0); r > 0; r--) {
-		if (prior.size() != img.n_entries) prior.assign(img.n_entries, 0);
 		for (size_t i = 0; i < hits.size(); i++)
-			if (hits[i] && img.ent_of[i] != DfaImage::kEvNone) prior[img.ent_of[i]] += hits[i];
-		opt.prior = prior.data(), opt.prior_entries = (uint32_t)prior.size();
+			if (hits[i] && img.ent_key[i] != DfaImage::kEvNone) prior[img.ent_key[i]] += hits[i];
+		pk.clear(), pc.clear();
+		for (const auto &kv : prior) pk.push_back(kv.first), pc.push_back(kv.second);
+		opt.prior_keys = pk.data(), opt.prior_counts = pc.data(), opt.prior_n = pk.size();
 		opt.corpus_bytes = off[D] - off[0] + D;
 		if (!c->trie.BuildDfa(&img, opt, &why)) return fail(c, TOKSCORE_E_VOCAB, why);
 		DfaRun(img, bytes, off, D, c->V, counts, total_tokens, &global_reads, &hits);
