@@ -2,6 +2,7 @@
 #include "dfa.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -15,6 +16,17 @@ namespace tokscore {
 
 namespace {
 inline uint8_t ascii_lower(uint8_t c) { return (c >= 'A' && c <= 'Z') ? (uint8_t)(c + 32) : c; } // SolutionFile.cpp:87-88
+
+struct PhaseTimer { // (TOKSCORE_TRACE_HOST: where the builder's time goes)
+	bool on = getenv("TOKSCORE_TRACE_HOST") != nullptr;
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	void mark(const char *what) {
+		if (!on) return;
+		const auto n = std::chrono::steady_clock::now();
+		fprintf(stderr, "BuildDfa: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+		t = n;
+	}
+};
 
 struct Entry {
 	uint32_t target; // state
@@ -47,6 +59,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	};
 	const uint32_t N = (uint32_t)first_child_.size();
 	if (N == 0) return fail("no vocabulary");
+	PhaseTimer pt;
 	// ---- codes: 0 = separator, 1 .. k = the bytes that label an edge, k + 1 = every other byte ----
 	bool is_label[256] = {};
 	for (const Edge &e : edges_) is_label[e.byte] = true;
@@ -140,6 +153,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 		F_dat.insert(F_dat.end(), F_stand[c].begin(), F_stand[c].end());
 		F_off[N + c + 1] = (uint32_t)F_dat.size();
 	}
+	pt.mark("failure function");
 	// ---- events ----
 	out->pool.clear();
 	uint32_t max_events = 1;
@@ -166,6 +180,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			M[s] = encode(ids);
 		}
 	}
+	pt.mark("event lists");
 	// ---- rows: real children, then the virtual entries of f's chain ----
 	std::vector<uint64_t> row_off(S + 1, 0);
 	std::vector<Entry> ent;
@@ -217,12 +232,26 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 		}
 		return (lo < row_off[s + 1] && ent[lo].code == c) ? (int64_t)lo : -1;
 	};
+	pt.mark("rows");
 	// ---- hotness: the sample run through the automaton (document boundaries ignored: layout only) ----
 	std::vector<uint64_t> w_row(S, 0);
 	std::vector<uint64_t> w_ent(ent.size(), 0);
 	std::vector<uint32_t> w_d1(ncodes, 0);
-	out->sample_steps = out->sample_virtual = out->sample_miss = 0;
-	if (opt.sample && opt.sample_bytes) {
+	const bool reuse = opt.reuse && opt.reuse != out && opt.reuse->vocab_tag == opt.vocab_tag && opt.reuse->sample_steps != 0 &&
+	                   opt.reuse->sample_w_ent.size() == ent.size() && opt.reuse->sample_w_row.size() == S;
+	if (reuse) {
+		for (size_t j = 0; j < ent.size(); j++) w_ent[j] = opt.reuse->sample_w_ent[j];
+		w_row = opt.reuse->sample_w_row;
+		out->sample_steps = opt.reuse->sample_steps, out->sample_virtual = opt.reuse->sample_virtual, out->sample_miss = opt.reuse->sample_miss;
+	} else out->sample_steps = out->sample_virtual = out->sample_miss = 0;
+	if (!reuse && opt.sample && opt.sample_bytes) {
+		// (a table entry-of(state, code) while it stays small: the search in the row cost 40 ns per sample byte)
+		std::vector<uint32_t> dense;
+		if ((uint64_t)S * ncodes <= (32u << 20)) {
+			dense.assign((size_t)S * ncodes, 0);
+			for (uint32_t s = 1; s < S; s++)
+				for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) dense[(size_t)s * ncodes + ent[j].code] = (uint32_t)j + 1;
+		}
 		uint32_t st = d1[0];
 		for (uint64_t i = 0; i < opt.sample_bytes; i++) {
 			const uint8_t c = code[ascii_lower(opt.sample[i])];
@@ -233,7 +262,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 				continue;
 			}
 			w_row[st]++;
-			const int64_t j = row_find(st, c);
+			const int64_t j = dense.empty() ? row_find(st, c) : (int64_t)dense[(size_t)st * ncodes + c] - 1;
 			if (j >= 0) {
 				w_ent[j]++;
 				out->sample_virtual += ent[j].virt;
@@ -248,6 +277,16 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	const bool sampled = out->sample_steps != 0;
 	// what an earlier image counted on the whole corpus: uses of entries LDS did not hold.  The sample's
 	// counts are brought to the corpus's scale first, so that the two can be compared.
+	out->vocab_tag = opt.vocab_tag;
+	if (!reuse) {
+		out->sample_w_row = w_row;
+		out->sample_w_ent.resize(ent.size());
+		for (size_t j = 0; j < ent.size(); j++) out->sample_w_ent[j] = (uint32_t)std::min<uint64_t>(w_ent[j], 0xFFFFFFFFull);
+	} else if (out->sample_w_ent.empty()) {
+		out->sample_w_ent = opt.reuse->sample_w_ent;
+		out->sample_w_row = opt.reuse->sample_w_row;
+	}
+	pt.mark("sample");
 	const bool have_prior = opt.prior_keys && opt.prior_counts && opt.prior_n != 0;
 	if (have_prior) {
 		if (sampled && opt.corpus_bytes > opt.sample_bytes) {
@@ -354,14 +393,17 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
 		return (double)w_row[a] / std::max<uint32_t>(1, nhot[a]) > (double)w_row[b] / std::max<uint32_t>(1, nhot[b]);
 	});
+	pt.mark("choice");
 	// ---- placement ----
 	struct Occ {
 		std::vector<uint8_t> used, base_used;
 		std::vector<uint32_t> next_free;
+		std::vector<uint64_t> bits; // `used`, one bit per slot: a row's entries are tested against 128 slots at a time
 		void ensure(uint64_t n) {
 			if (used.size() < n) {
 				const uint64_t old = used.size(), m = std::max<uint64_t>(n, std::max<uint64_t>(4096, old * 2));
 				used.resize(m, 0);
+				bits.resize(m / 64 + 4, 0);
 				base_used.resize(m, 0);
 				next_free.resize(m);
 				for (uint64_t i = old; i < m; i++) next_free[i] = (uint32_t)i;
@@ -385,8 +427,17 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			ensure(t + 1);
 			return used[t] != 0;
 		}
+		// does a row whose entries' codes are the bits of (m0, m1) fit at base b?
+		bool fits(uint64_t b, uint64_t m0, uint64_t m1) {
+			ensure(b + 130);
+			const uint64_t i = b >> 6, sh = b & 63;
+			const uint64_t w0 = sh ? (bits[i] >> sh) | (bits[i + 1] << (64 - sh)) : bits[i];
+			const uint64_t w1 = sh ? (bits[i + 1] >> sh) | (bits[i + 2] << (64 - sh)) : bits[i + 1];
+			return ((w0 & m0) | (w1 & m1)) == 0;
+		}
 		void take(uint64_t t) {
 			ensure(t + 2);
+			bits[t >> 6] |= 1ull << (t & 63);
 			used[t] = 1;
 			next_free[t] = (uint32_t)(t + 1);
 		}
@@ -460,15 +511,16 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			return true;
 		}
 		const uint32_t c0 = e[lead].code;
+		uint64_t m0 = 0, m1 = 0; // the codes of the entries to store
+		for (uint32_t i = lead; i < nc; i++)
+			if (in(i)) (e[i].code < 64 ? m0 : m1) |= 1ull << (e[i].code & 63);
 		uint64_t t = occ.find_free(std::max<uint64_t>(lo + c0, (uint64_t)c0 + 1));
 		uint64_t b = 0;
 		for (uint32_t tries = 0;; tries++) {
 			b = t - c0;
 			if (hi && b >= hi) return false;
-			bool ok = !occ.base_taken(b);
-			for (uint32_t i = lead; ok && i < nc; i++) ok = !in(i) || !occ.is_used(b + e[i].code);
-			if (ok) break;
-			if (tries >= 512 && !hi) { // (deep vocabularies: see VocabTrie::Pack) beyond everything placed so far
+			if (!occ.base_taken(b) && occ.fits(b, m0, m1)) break;
+			if (tries >= 24 && !hi) { // (the global array need not be tight: soon beyond everything placed so far -- 512 tries cost 200 ms)
 				for (b = std::max<uint64_t>(occ.max_base + 1, lo);; b++) {
 					bool fits = !occ.base_taken(b);
 					for (uint32_t i = lead; fits && i < nc; i++) fits = !in(i) || !occ.is_used(b + e[i].code);
@@ -529,6 +581,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			else klass[s] = 1;                            // no row at all: every lookup misses, rightly
 		}
 	}
+	pt.mark("placement (LDS)");
 	// the whole automaton in the global array
 	G.max_base = hot_cap - 1;
 	G.base_cursor = hot_cap;
@@ -554,6 +607,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 		for (uint64_t j = row_off[s]; all && j < row_off[s + 1]; j++) all = stored(s, j);
 		partial_row[s] = !all;
 	}
+	pt.mark("placement (global)");
 	// ---- the image ----
 	out->ncodes = ncodes;
 	out->stride = stride;
@@ -613,6 +667,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			else out->real_slots++;
 		}
 	}
+	pt.mark("image");
 	out->sample_cold = sampled && !have_prior ? cold_steps : 0;
 	out->max_events = max_events;
 	out->valid = true;

@@ -510,18 +510,28 @@ __global__ void __launch_bounds__(1024) dfa_hist_kernel(DfaDev A, StreamDev Qm, 
 	if (!arrivals) {
 		// rows first, first + step, ... of a batch, eight in flight
 		auto some_rows = [&](uint32_t bt, uint32_t first_row, uint32_t step) {
+			const uint4 *rows = vec + (uint64_t)bt * kStreamBatch * vecs_per_block + lane;
+			// (the first rows are asked for together with the fill word that says how many of them count: one round
+			// trip instead of two; a batch's 32 rows are all readable)
+			uint4 v[kRowsInFlight];
+#pragma unroll
+			for (int u = 0; u < kRowsInFlight; u++) {
+				const uint32_t r = first_row + u * step;
+				v[u] = r < kStreamBatch ? rows[(size_t)r * 64] : uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+			}
 			uint32_t live = Q.fill[bt]; // entries written to the batch (what follows them was never written, or is not counted)
 			if (live > kDfaBatchEntries) live = kDfaBatchEntries;
 			live = uni32(live);
 			const uint32_t live_rows = (live + 511) / 512;
-			const uint4 *rows = vec + (uint64_t)bt * kStreamBatch * vecs_per_block + lane;
 			for (uint32_t r0 = first_row; r0 < live_rows; r0 += kRowsInFlight * step) {
-				uint4 v[kRowsInFlight];
 #pragma unroll
 				for (int u = 0; u < kRowsInFlight; u++) {
 					const uint32_t r = r0 + u * step;
-					v[u] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-					if (r < live_rows) v[u] = blank(rows[(size_t)r * 64], r * 512 + lane * 8, live);
+					if (r0 != first_row) {
+						v[u] = uint4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+						if (r < live_rows) v[u] = rows[(size_t)r * 64];
+					}
+					if (r < live_rows) v[u] = blank(v[u], r * 512 + lane * 8, live);
 				}
 #pragma unroll
 				for (int u = 0; u < kRowsInFlight; u++)
@@ -619,36 +629,32 @@ __global__ void __launch_bounds__(1024) dfa_reduce_kernel(DfaDev A, const int16_
 	const uint32_t *slab2 = reinterpret_cast<const uint32_t *>(slab);
 	int acc[4] = {0, 0, 0, 0}; // miss lo / hi, arrival lo / hi (rows x 32,767 fits easily)
 	if (k < width) {
-		uint32_t r = grp;
-		for (; r + 3 * kDfaReduceGroups < split; r += 4 * kDfaReduceGroups) { // (four rows in flight: the loop waits on memory, not on adds)
-			const uint32_t a0 = slab2[(size_t)r * stride + k / 2];
-			const uint32_t a1 = slab2[(size_t)(r + kDfaReduceGroups) * stride + k / 2];
-			const uint32_t a2 = slab2[(size_t)(r + 2 * kDfaReduceGroups) * stride + k / 2];
-			const uint32_t a3 = slab2[(size_t)(r + 3 * kDfaReduceGroups) * stride + k / 2];
-			acc[0] += (int)(a0 & 0xFFFFu) + (int)(a1 & 0xFFFFu) + (int)(a2 & 0xFFFFu) + (int)(a3 & 0xFFFFu);
-			acc[1] += (int)(a0 >> 16) + (int)(a1 >> 16) + (int)(a2 >> 16) + (int)(a3 >> 16);
-		}
-		for (; r < rows; r += kDfaReduceGroups) {
-			const uint32_t a = slab2[(size_t)r * stride + k / 2];
-			const int o = r < split ? 0 : 2;
-			acc[o] += (int)(a & 0xFFFFu);
-			acc[o + 1] += (int)(a >> 16);
+		for (uint32_t r = grp; r < rows; r += 8 * kDfaReduceGroups) { // (eight rows in flight: the loop waits on memory, not on adds)
+			uint32_t a[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				const uint32_t ru = r + u * kDfaReduceGroups;
+				a[u] = ru < rows ? slab2[(size_t)ru * stride + k / 2] : 0u;
+			}
+#pragma unroll
+			for (int u = 0; u < 8; u++) {
+				const int o = r + u * kDfaReduceGroups < split ? 0 : 2;
+				acc[o] += (int)(a[u] & 0xFFFFu);
+				acc[o + 1] += (int)(a[u] >> 16);
+			}
 		}
 	}
 #pragma unroll
 	for (int q = 0; q < 4; q++) part[grp][lane][q] = acc[q];
 	__syncthreads();
+	// one (key, kind) per thread of the first four waves: a booking is three dependent reads (event, list length,
+	// ids) before its atomics, and four of them one after the other per lane took 10 of the kernel's 17 us
 	long long mine = 0;
-	if (grp == 0 && k < width) {
-		for (uint32_t g = 1; g < kDfaReduceGroups; g++)
-#pragma unroll
-			for (int q = 0; q < 4; q++) acc[q] += part[g][lane][q];
-		mine += book_event_ids(A, A.ev_miss[k], acc[0], out);
-		mine += book_event_ids(A, A.ev_arr[k], acc[2], out);
-		if (k + 1 < width) {
-			mine += book_event_ids(A, A.ev_miss[k + 1], acc[1], out);
-			mine += book_event_ids(A, A.ev_arr[k + 1], acc[3], out);
-		}
+	if (grp < 4) {
+		const uint32_t q = grp, key = k + (q & 1u);
+		int sum = 0;
+		for (uint32_t g = 0; g < kDfaReduceGroups; g++) sum += part[g][lane][q];
+		if (sum != 0 && key < width) mine = book_event_ids(A, (q < 2 ? A.ev_miss : A.ev_arr)[key], sum, out);
 	}
 	add_block_total(mine, out, total_index);
 }
@@ -752,7 +758,9 @@ bool plan_dfa_scan(uint32_t hot_slots, uint64_t prep_total, uint32_t num_cus, ui
 }
 
 uint32_t dfa_lds_slots_max(uint32_t cap) {
-	constexpr uint32_t kMaxLds = 40000; // slots: what one histogram pass has bins for (kernels_stream.hip: histogram_slots)
+	// slots: 4 bytes each in the scan's LDS and a 4-byte bin each, plus 64 spare words and a few static ones, in
+	// dfa_hist_kernel's -- all of a CU's 160 KiB but a few hundred bytes
+	constexpr uint32_t kMaxLds = 40832;
 	return cap ? std::min<uint32_t>(kMaxLds, std::max<uint32_t>(cap, 512)) : kMaxLds;
 }
 

@@ -873,7 +873,12 @@ bool upload_dfa_image(tokscore_ctx *c) {
 	if (!c->dfa_prior.empty()) opt.prior_keys = c->dfa_prior_keys.data(), opt.prior_counts = c->dfa_prior_counts.data(), opt.prior_n = c->dfa_prior.size();
 	std::string why;
 	const auto t0 = std::chrono::steady_clock::now();
-	if (!c->trie.BuildDfa(&c->dimg, opt, &why)) return false;
+	// (a new image object each time: the old one lends its sample counts while the vocabulary is what it was built from)
+	DfaImage fresh;
+	opt.vocab_tag = c->toggle_version + 1;
+	if (c->dimg.valid) opt.reuse = &c->dimg;
+	if (!c->trie.BuildDfa(&fresh, opt, &why)) return false;
+	c->dimg = std::move(fresh);
 	c->dfa_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	const DfaImage &g = c->dimg;
 	const size_t n = g.nslots, nh = g.hot_slots, ne = g.ev_miss.size();
