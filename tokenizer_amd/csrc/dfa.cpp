@@ -363,10 +363,10 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 		double lo = 0.25, hi = 1;
 		for (uint64_t j : cand) hi = std::max(hi, (double)w_ent[j] + 1);
 		for (uint32_t s = 1; s < S; s++) hi = std::max(hi, (double)w_miss[s] + 1);
-		if (choose(lo, false) > 0.97 * room) {
+		if (choose(lo, false) > 0.985 * room) {
 			for (int it = 0; it < 48 && hi - lo > 1e-3 * lo; it++) {
 				const double mid = std::sqrt(lo * hi);
-				if (choose(mid, false) > 0.97 * room) lo = mid;
+				if (choose(mid, false) > 0.985 * room) lo = mid;
 				else hi = mid;
 			}
 			lo = hi;
@@ -381,7 +381,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			klass[s] = nhot[s] ? (ncold[s] ? 2 : 1) : 0;
 		};
 		for (uint64_t j : cand) {
-			if (taken + 1 > 0.985 * room) break;
+			if (taken + 1 > 0.995 * room) break;
 			if (!sel[j]) sel[j] = 1, taken++;
 		}
 		for (uint32_t s = 1; s < S; s++)
