@@ -961,6 +961,7 @@ void ensure_dfa(tokscore_ctx *c) {
 	uint32_t *d_flags = nullptr;
 	uint32_t flags = 1;
 	c->dslab_blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, c->total / (256 * 1024)));
+	c->dslab_blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(2, env_u64("TOKSCORE_DFA_SLAB_BLOCKS", c->dslab_blocks)));
 	bool ok = hipMalloc((void **)&c->d_dcodes, lin_bytes) == hipSuccess && hipMalloc((void **)&d_flags, sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc(&c->d_dtcodes, covered) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dstate, 3 * nranges * sizeof(uint2)) == hipSuccess &&

@@ -59,6 +59,8 @@ def big(name, config, tokens, corpus, off, sample_bytes=8_000_000):
     info = s.info()
     evals = []
     again = None
+    for _ in range(3):  # (the automaton scan chooses again what LDS holds after its first two evaluations)
+        again = s.score()
     for _ in range(5):
         again = s.score()
         evals.append(s.last_timing())
@@ -81,7 +83,8 @@ def big(name, config, tokens, corpus, off, sample_bytes=8_000_000):
            "lds_slots": int(info.trie_lds_slots), "scan_path": int(info.scan_path), "chunks": int(info.chunks),
            "total_tokens": int(tt), "set_corpus_s": t1 - t0, "first_evaluation_s": first_s,
            "eval_ms": tm[0], "scan_ms": tm[1], "fixup_ms": tm[2], "hist_reduce_ms": tm[3],
-           "GBps_eval": tby / tm[0] / 1e6 if tm[0] else 0.0, "sample_bytes": int(off[d]), "sample_parity": sample_ok,
+           "GBps_eval": tby / tm[0] / 1e6 if tm[0] else 0.0, "roofline_frac_scan": (tby / tm[1] / 1e6 / 8000.0) if tm[1] else 0.0,
+           "automaton_scan": int(info.dfa_active), "sample_bytes": int(off[d]), "sample_parity": sample_ok,
            "rare_token_rescored_chunks": resc, **props}
     s.close()
     print(json.dumps(rec), flush=True)
@@ -108,6 +111,12 @@ def main_big(wiki_mb, utf8_mb):
         corpus, off = synth.random_utf8(int(utf8_mb * 1e6), seed=355)
         tokens = synth.sample_vocab(corpus[: 50_000_000], 128000)
         ok &= big("utf8", "config 4: random UTF-8 %.0f MB, V=128k sampled from the corpus" % utf8_mb, tokens, corpus, off)
+    # config 5's corpus (CJK-heavy, V = 32 k) and the reference annealer's own vocabulary on the kind of text it was made from
+    corpus, off = synth.cjk_heavy(400_000_000, seed=5)
+    ok &= big("cjk", "config 5 corpus: CJK-heavy 400 MB, V=32k", synth.build_vocab(corpus[:2_000_000], 32000), corpus, off)
+    corpus, off = synth.wiki_like(100_000_000, seed=1234, n_words=20_000)
+    ok &= big("annealed", "tests/golden/wiki_annealed vocabulary (30,275 tokens, 124,789 trie nodes) on wiki-like 100 MB (seed 1234, 20,000 words)",
+              O.load_golden("wiki_annealed")["tokens"], corpus, off)
     print("ALL OK" if ok else "MISMATCH")
     sys.exit(0 if ok else 1)
 
