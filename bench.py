@@ -99,15 +99,14 @@ def split_shard(corpus, off, rank, world):
 def settle(scorer, out_ptr, stream_ptr, sync):
     """Before any timing: the evaluations in which the library still arranges itself -- the first one repairs
     every range's entry state, and the automaton scan lays LDS out again from its own counters after the
-    first two (tokscore_info.dfa_relayouts).  -> milliseconds of each evaluation, host clock."""
+    first one (tokscore_info.dfa_relayouts).  -> milliseconds of each evaluation, host clock."""
     ms = []
-    for _ in range(6):
+    for _ in range(7):
         t0 = time.perf_counter()
         scorer.score_async(out_ptr, stream_ptr)
         sync()
         ms.append((time.perf_counter() - t0) * 1e3)
-        i = scorer.info()
-        if len(ms) >= 2 and (not i.dfa_active or i.dfa_relayouts >= 2) and ms[-1] < 2 * min(ms):
+        if len(ms) >= 3 and abs(ms[-1] - ms[-2]) < 0.3 * ms[-2]:  # (steady: no re-layout, no repairs in the last two)
             break
     return ms
 

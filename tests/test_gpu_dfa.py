@@ -61,7 +61,7 @@ def test_automaton_scan_matches_oracle(chains, lds):
     _check(s, voc, corpus, off, "second evaluation (what LDS holds chosen again from the first one's counters)")
     _check(s, voc, corpus, off, "third evaluation")
     _check(s, voc, corpus, off, "fourth evaluation (entries as the third left them)")
-    assert s.info().dfa_relayouts == 2
+    assert s.info().dfa_relayouts == 1
     s.close()
 
 

@@ -51,7 +51,7 @@ def test_deltas_equal_oracle_differences(env, monkeypatch):
         s.set_vocab(*synth.pack_vocab(tokens))
         s.set_corpus(corpus, off)
         base = s.score()
-        assert s.info().base_scan_path == (1 if env.get("TOKSCORE_SCAN") == "tile" else 2)
+        assert s.info().dfa_active == 1 and s.info().base_scan_path == 0  # (the automaton scan needs no plan; moves do: below)
         enabled = np.ones(V, dtype=bool)
         rng = np.random.default_rng(7)
         multi = [i for i, t in enumerate(tokens) if len(t) >= 2]
@@ -63,6 +63,7 @@ def test_deltas_equal_oracle_differences(env, monkeypatch):
         en[3] = 1                                     # enabling what is enabled: no move
         got = _check_moves(s, tokens, enabled, corpus, off, idx, en)
         assert got[3] == 0 and got[-1] == got[0]
+        assert s.info().base_scan_path == (1 if env.get("TOKSCORE_SCAN") == "tile" else 2)
         assert (s.info().toggle_streams > 0) == (env.get("TOKSCORE_SCAN") != "tile"), "which path served the call"
         assert any(int(d) != 0 for d in got)
         # nothing was changed by asking

@@ -145,6 +145,10 @@ struct tokscore_ctx {
 
 	// plan
 	bool plan_valid = false;
+	// what made the plan invalid (another corpus, another vocabulary, a repacked trie) also ends the automaton
+	// scan's image and buffers, which live apart from the plan: the plan of the other scan paths is only built
+	// when something needs it (0.55 s per GB), the automaton serves full evaluations without it
+	bool dfa_invalid = false;
 	int scan_path = 0; // 0 generic, 1 tile
 	bool force_generic = false; // set after a token-stream overflow
 	TileScanPlan tile = {};
@@ -242,6 +246,7 @@ struct tokscore_ctx {
 	uint32_t dfa_chains = 0;
 	uint32_t dfa_lds_cap = 0;
 	bool dfa_relayout_on = true;   // TOKSCORE_DFA_RELAYOUT=0: what LDS holds stays as the host's sample chose it
+	uint32_t dfa_relayouts_max = 1; // TOKSCORE_DFA_RELAYOUTS
 	// the automaton serves a vocabulary while the sample's lookups beyond LDS and its arrivals on virtual entries stay
 	// below these shares (parts per million; TOKSCORE_DFA_MAX_COLD_PPM, TOKSCORE_DFA_MAX_VIRTUAL_PPM)
 	uint64_t dfa_max_cold_ppm = 10000, dfa_max_virtual_ppm = 30000;
@@ -264,7 +269,7 @@ struct tokscore_ctx {
 	std::map<uint32_t, uint32_t> dfa_prior; // uses of entries that LDS did not hold, by DfaImage::ent_key (DfaOptions::prior_*)
 	std::vector<uint32_t> dfa_prior_keys, dfa_prior_counts; // ... flattened for the builder
 	uint32_t dfa_evals = 0;          // evaluations on the image as it is
-	uint32_t dfa_relayouts = 0;      // images built from counters (at most kDfaRelayouts per vocabulary state)
+	uint32_t dfa_relayouts = 0;      // images built from counters (at most dfa_relayouts_max per vocabulary)
 	uint64_t dfa_second_hits = 0;    // lookups the global array answered with a hit, in the evaluations counted last
 	double dfa_build_ms = 0, dfa_plan_ms = 0;
 
@@ -310,6 +315,7 @@ void free_corpus(tokscore_ctx *c) {
 	c->own_corpus = false;
 	c->corpus_set = false;
 	c->plan_valid = false;
+	c->dfa_invalid = true;
 }
 
 // The stream scan's copy of the corpus (kernels_stream.hip: prep_corpus_kernel), built once per
@@ -370,7 +376,6 @@ void free_plan(tokscore_ctx *c) {
 	// nothing enqueued by an earlier asynchronous evaluation may still use these buffers
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	if (c->side) (void)hipStreamSynchronize(c->side);
-	free_dfa(c);
 	if (c->d_chunk_begin) (void)hipFree(c->d_chunk_begin);
 	if (c->d_chunk_state) (void)hipFree(c->d_chunk_state);
 	if (c->d_chunk_first_doc) (void)hipFree(c->d_chunk_first_doc);
@@ -484,6 +489,7 @@ int ensure_trie(tokscore_ctx *c) {
 		c->packed_valid = true;
 		c->device_trie_valid = false;
 		c->plan_valid = false;
+		c->dfa_invalid = true;
 		c->simg_valid = c->trie.PackStream(&c->simg);
 	}
 	if (c->hostonly) return TOKSCORE_OK;
@@ -1045,7 +1051,8 @@ bool refresh_dfa(tokscore_ctx *c) { return rebuild_dfa(c); }
 // After an evaluation on the automaton: which entries of the global array the corpus really uses (the
 // host's sample saw 2 MB of it).  Where that is more than a few lookups in 100,000, LDS is laid out
 // again with those entries counted in (results never depend on it: only where a lookup is answered).
-constexpr uint32_t kDfaRelayouts = 2;
+// (a second re-layout was measured to change nothing: 7.5 k second looks per 20 MB after one, 7.9 k after two)
+constexpr uint32_t kDfaRelayoutsDefault = 1;
 constexpr uint32_t kDfaArrivalBlocks = 16; // workgroups of the histogram launch that bin the arrival stream (a few percent of the miss stream's entries at most)
 bool relayout_dfa(tokscore_ctx *c) {
 	(void)hipDeviceSynchronize();
@@ -1108,13 +1115,14 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 	int st = ensure_trie(c);
 	if (st) return st;
 	if (!c->corpus_set) return fail(c, TOKSCORE_E_STATE, "corpus not set");
-	st = ensure_plan(c);
-	if (st) return st;
-	st = apply_pending(c, s);
-	if (st) return st;
 	c->state_valid = false;
 	// the automaton scan, while its image is the vocabulary as it is; after toggles the plan's own scan
 	// (which patches one slot per toggle) until two full evaluations in a row met no new toggle
+	if (c->dfa_invalid) {
+		(void)hipDeviceSynchronize();
+		free_dfa(c);
+		c->dfa_invalid = false;
+	}
 	ensure_dfa(c);
 	bool use_dfa = c->dfa_state == 1 && c->dfa_enabled;
 	if (use_dfa && c->dfa_version != c->toggle_version) {
@@ -1126,7 +1134,7 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 				c->dfa_state = -1;
 			}
 		}
-	} else if (use_dfa && c->dfa_evals >= 1 && c->dfa_relayouts < kDfaRelayouts && c->dfa_relayout_on) {
+	} else if (use_dfa && c->dfa_evals >= 1 && c->dfa_relayouts < c->dfa_relayouts_max && c->dfa_relayout_on) {
 		if (!relayout_dfa(c)) {
 			free_dfa(c);
 			c->dfa_state = -1;
@@ -1134,6 +1142,13 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		}
 	}
 	if (use_dfa) c->dfa_evals++;
+	// the plan of the other scan paths: only when this evaluation runs on them (or a toggle / move / count call asks)
+	if (!use_dfa) {
+		st = ensure_plan(c);
+		if (st) return st;
+	}
+	st = apply_pending(c, s); // (the device trie and stream image of the other paths: kept up to date whichever path runs)
+	if (st) return st;
 	TrieDev T = trie_dev(c);
 	CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
 	ChunkState S{c->d_chunk_begin, c->d_chunk_state, c->d_chunk_state + (c->nchunks + 1),
@@ -1533,6 +1548,7 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->dfa_chains = (uint32_t)env_u64("TOKSCORE_DFA_CHAINS", 0);
 	c->dfa_lds_cap = (uint32_t)env_u64("TOKSCORE_DFA_LDS", 0);
 	c->dfa_relayout_on = env_u64("TOKSCORE_DFA_RELAYOUT", 1) != 0;
+	c->dfa_relayouts_max = (uint32_t)env_u64("TOKSCORE_DFA_RELAYOUTS", kDfaRelayoutsDefault);
 	c->fix_epoch = (uint32_t)(env_u64("TOKSCORE_FIX_EPOCH_START", 0) % 65536u); // (tests: start next to the 16-bit tag's wrap)
 	c->fix_epoch_wrapped = c->fix_epoch != 0;
 	c->dfa_max_cold_ppm = env_u64("TOKSCORE_DFA_MAX_COLD_PPM", c->dfa_max_cold_ppm);
@@ -1567,6 +1583,7 @@ void tokscore_destroy(tokscore_ctx *c) {
 		(void)hipSetDevice(c->device);
 		(void)hipStreamSynchronize(c->stream);
 		if (c->side) (void)hipStreamSynchronize(c->side);
+		free_dfa(c);
 		free_plan(c);
 		free_corpus(c);
 		if (c->d_slots) (void)hipFree(c->d_slots);
@@ -1605,6 +1622,7 @@ int tokscore_set_vocab(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *of
 	c->packed_valid = false;
 	c->device_trie_valid = false;
 	c->plan_valid = false;
+	c->dfa_invalid = true;
 	c->pending.clear();
 	c->pending_s.clear();
 	c->simg_valid = false;
@@ -1665,6 +1683,8 @@ int tokscore_set_corpus(tokscore_ctx *c, const uint8_t *bytes, const uint64_t *o
 	if (!c || !off) return fail(c, TOKSCORE_E_ARG, "null corpus buffers");
 	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
 	(void)hipSetDevice(c->device);
+	(void)hipDeviceSynchronize(); // (an evaluation on a caller's stream may still read what is freed here)
+	free_dfa(c);
 	free_plan(c);
 	free_corpus(c);
 	c->state_valid = false;
@@ -1700,6 +1720,8 @@ int tokscore_set_corpus_device(tokscore_ctx *c, const void *d_bytes, const void 
 	if (!c || !d_off || (!d_bytes && total_bytes)) return fail(c, TOKSCORE_E_ARG, "null corpus buffers");
 	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
 	(void)hipSetDevice(c->device);
+	(void)hipDeviceSynchronize(); // (an evaluation on a caller's stream may still read what is freed here)
+	free_dfa(c);
 	free_plan(c);
 	free_corpus(c);
 	c->state_valid = false;
@@ -1739,7 +1761,7 @@ int tokscore_async_status(tokscore_ctx *c, void *stream, int *overflowed) {
 	(void)hipSetDevice(c->device);
 	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
 	uint32_t words[2] = {0, 0};
-	const uint32_t *cursor = !c->plan_valid ? nullptr : (c->dfa_used_last ? c->d_dcursor : (c->scan_path >= 1 ? c->d_cursor : nullptr));
+	const uint32_t *cursor = c->dfa_used_last ? c->d_dcursor : (c->plan_valid && c->scan_path >= 1 ? c->d_cursor : nullptr);
 	if (cursor) HIP_TRY(c, hipMemcpyAsync(words, cursor, sizeof words, hipMemcpyDeviceToHost, s));
 	HIP_TRY(c, hipStreamSynchronize(s));
 	*overflowed = words[1] != 0;
@@ -1769,6 +1791,7 @@ int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, ui
 		// adversarial input blew the stream bound: redo this evaluation on the generic path
 		c->force_generic = true;
 		c->plan_valid = false;
+		c->dfa_invalid = true;
 		return tokscore_score(c, counts, total_tokens, total_bytes);
 	}
 	if (st) return st;
@@ -1791,6 +1814,12 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 	if (!c || !counts) return fail(c, TOKSCORE_E_ARG, "null output");
 	if (c->hostonly) return fail(c, TOKSCORE_E_NO_DEVICE, tokscore_strerror(TOKSCORE_E_NO_DEVICE));
 	(void)hipSetDevice(c->device);
+	if (!c->plan_valid && c->state_valid && c->corpus_set && c->vocab_set && !c->hostonly) {
+		// full evaluations on the automaton scan need no plan: this call does (chunk boundaries, the occurrence index)
+		int pst = ensure_trie(c);
+		if (!pst) pst = ensure_plan(c);
+		if (pst) return pst;
+	}
 	const bool eligible = c->state_valid && c->plan_valid && c->packed_valid && c->device_trie_valid && c->d_vocab_valid &&
 	                      c->scan_path >= 1 && (c->scan_path == 2 ? c->chunks_synced : c->unsynced == 0) && c->uniform_chunks && c->pending.size() <= kMaxPatch &&
 	                      !c->knob_noincr;
@@ -1941,6 +1970,7 @@ int tokscore_score_incremental(tokscore_ctx *c, uint64_t *counts, uint64_t *tota
 		if (st) {
 			c->force_generic = true;
 			c->plan_valid = false;
+			c->dfa_invalid = true;
 			return tokscore_score(c, counts, total_tokens, total_bytes);
 		}
 	}
@@ -2354,7 +2384,7 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 	info->rescored_chunks = c->rescored_chunks;
 	info->toggle_streams = c->toggle_items;
 	info->base_scan_path = info->scan_path;
-	if (c->plan_valid && c->dfa_state == 1) {
+	if (c->dfa_state == 1 && !c->dfa_invalid) {
 		info->dfa_slots = c->dimg.nslots;
 		info->dfa_lds_slots = c->dimg.hot_slots;
 		info->dfa_lds_used = c->dimg.hot_used;
