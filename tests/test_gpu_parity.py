@@ -81,9 +81,9 @@ DFA_CONFIGS = [
     dict(FORCE, TOKSCORE_DFA_CHAINS="2", TOKSCORE_DFA_LDS="600"),
     dict(FORCE, TOKSCORE_SCAN="tile", TOKSCORE_DFA="1", TOKSCORE_DFA_LDS="2000"),
 ]
-# goldens the automaton does not take (the plan's scan serves them): more than 125 distinct edge bytes (the
-# label has 7 bits)
-DFA_EXCEPT = {"random_utf8"}
+# goldens the automaton does not take (the plan's scan serves them): none any more (random_utf8's 190 distinct
+# edge bytes fit the label's byte since it became one)
+DFA_EXCEPT = set()
 CONFIGS = CONFIGS + DFA_CONFIGS
 # goldens whose text has sync points and whose trie fits LDS: the stream scan must be the path taken
 STREAM_CASES = {"ascii_caps", "cjk_heavy", "short_docs", "prefix_greedy"}  # (wiki_annealed: 125k trie nodes, random_utf8: > 125 edge labels: tile scan)

@@ -67,7 +67,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	uint32_t k = 0;
 	for (uint32_t b = 1; b < 256; b++) k += is_label[b] ? 1 : 0;
 	const uint32_t ncodes = k + 2;
-	if (ncodes > DfaImage::kMaxCodes) return fail("too many distinct edge bytes (the label has 7 bits)");
+	if (ncodes > DfaImage::kMaxCodes) return fail("too many distinct edge bytes (the label is a byte, all ones = empty)");
 	const uint32_t other = k + 1;
 	{
 		uint32_t next = 1;
@@ -403,7 +403,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			if (used.size() < n) {
 				const uint64_t old = used.size(), m = std::max<uint64_t>(n, std::max<uint64_t>(4096, old * 2));
 				used.resize(m, 0);
-				bits.resize(m / 64 + 4, 0);
+				bits.resize(m / 64 + 8, 0);
 				base_used.resize(m, 0);
 				next_free.resize(m);
 				for (uint64_t i = old; i < m; i++) next_free[i] = (uint32_t)i;
@@ -427,13 +427,14 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			ensure(t + 1);
 			return used[t] != 0;
 		}
-		// does a row whose entries' codes are the bits of (m0, m1) fit at base b?
-		bool fits(uint64_t b, uint64_t m0, uint64_t m1) {
-			ensure(b + 130);
+		// does a row whose entries' codes are the bits of m[0 .. 3] fit at base b?
+		bool fits(uint64_t b, const uint64_t m[4]) {
+			ensure(b + 260);
 			const uint64_t i = b >> 6, sh = b & 63;
-			const uint64_t w0 = sh ? (bits[i] >> sh) | (bits[i + 1] << (64 - sh)) : bits[i];
-			const uint64_t w1 = sh ? (bits[i + 1] >> sh) | (bits[i + 2] << (64 - sh)) : bits[i + 1];
-			return ((w0 & m0) | (w1 & m1)) == 0;
+			uint64_t hit = 0;
+			for (int q = 0; q < 4; q++)
+				if (m[q]) hit |= (sh ? (bits[i + q] >> sh) | (bits[i + q + 1] << (64 - sh)) : bits[i + q]) & m[q];
+			return hit == 0;
 		}
 		void take(uint64_t t) {
 			ensure(t + 2);
@@ -511,15 +512,15 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			return true;
 		}
 		const uint32_t c0 = e[lead].code;
-		uint64_t m0 = 0, m1 = 0; // the codes of the entries to store
+		uint64_t mk[4] = {0, 0, 0, 0}; // the codes of the entries to store
 		for (uint32_t i = lead; i < nc; i++)
-			if (in(i)) (e[i].code < 64 ? m0 : m1) |= 1ull << (e[i].code & 63);
+			if (in(i)) mk[e[i].code >> 6] |= 1ull << (e[i].code & 63);
 		uint64_t t = occ.find_free(std::max<uint64_t>(lo + c0, (uint64_t)c0 + 1));
 		uint64_t b = 0;
 		for (uint32_t tries = 0;; tries++) {
 			b = t - c0;
 			if (hi && b >= hi) return false;
-			if (!occ.base_taken(b) && occ.fits(b, m0, m1)) break;
+			if (!occ.base_taken(b) && occ.fits(b, mk)) break;
 			if (tries >= 24 && !hi) { // (the global array need not be tight: soon beyond everything placed so far -- 512 tries cost 200 ms)
 				for (b = std::max<uint64_t>(occ.max_base + 1, lo);; b++) {
 					bool fits = !occ.base_taken(b);

@@ -34,18 +34,21 @@
 namespace tokscore {
 
 struct DfaImage {
-	// slot word: kArr : 1 | 0 : 7 | partial : 1 | label (code) : 7 | base : 16.  The state a word stands
+	// slot word: kArr : 1 | partial : 1 | 0 : 6 | label (code) : 8 | base : 16.  The state a word stands
 	// for looks its next byte up at slot base + code OF THE LDS ARRAY; `partial` says that LDS does not
 	// hold that state's row completely, so a miss there proves nothing.  Empty slots carry the all-ones
-	// label, which no code equals.  Bits 24 - 30 are zero in every word (the scan's loop marks lanes there:
-	// one compare of the top byte then finds both the marked lanes and the arrivals on kArr entries).
+	// label, which no code equals.  The label is a byte of its own (the scan compares it with the corpus
+	// byte in one instruction).  The scan's loop gives the state a lane takes after a miss the top byte of the
+	// state left, shifted left by one: the sign bit then says "that state was partial" (kArr drops out, and so
+	// does the mark itself one step later), so that one sign test finds both the lanes whose miss LDS may not
+	// decide (sign and miss) and the arrivals on kArr entries (sign and hit), and nothing else.
 	static constexpr uint32_t kLabelShift = 16;
-	static constexpr uint32_t kLabelMask = 0x7Fu;
+	static constexpr uint32_t kLabelMask = 0xFFu;
 	static constexpr uint32_t kArr = 0x80000000u;
-	static constexpr uint32_t kPartial = 0x800000u;
+	static constexpr uint32_t kPartial = 0x40000000u;
 	static constexpr uint32_t kBaseMask = 0xFFFFu;
-	static constexpr uint32_t kEmptyWord = 0x7F0000u;
-	static constexpr uint32_t kMaxCodes = 127;      // codes 0 .. ncodes - 1 in the label's 7 bits, all ones = empty
+	static constexpr uint32_t kEmptyWord = 0xFF0000u;
+	static constexpr uint32_t kMaxCodes = 255;      // codes 0 .. ncodes - 1 in the label's byte, all ones = empty
 	static constexpr uint32_t kMaxHot = 65536;      // (the base's 16 bits)
 	static constexpr uint64_t kMaxSlots = 1u << 23;
 	// events: kEvNone = nothing to count, id < 2^31 = one token id, kEvList | o = pool[o] ids at pool[o + 1 ..]

@@ -225,7 +225,7 @@ void launch_histogram_events(const StreamDev &Q, uint32_t nslots, const uint32_t
 
 // kernels_dfa.hip -- full evaluation on the one-transition-per-byte automaton (dfa.h)
 struct DfaDev {
-	const uint32_t *hot;     // [hot_slots, padded to 16 bytes] the LDS array (dfa.h: kArr | 0 : 7 | partial | label : 7 | base : 16)
+	const uint32_t *hot;     // [hot_slots, padded to 16 bytes] the LDS array (dfa.h: kArr | partial | 0 : 6 | label : 8 | base : 16)
 	const uint2 *slot;       // [nslots] the global array: .x the entry's word, .y its target's global base; rows at bases >= hot_slots
 	const uint32_t *gof;     // [hot_slots] by LDS base: the state's global base
 	const uint32_t *ev_miss; // [nslots] by state key (LDS base, or global base under cold_base): leaving the state by a miss

@@ -37,7 +37,7 @@ namespace tokscore {
 namespace {
 
 constexpr uint32_t kDfaBatchEntries = kStreamBatch * 512; // u16 entries of one stream batch (32 KiB)
-constexpr uint32_t kArr = 0x80000000u, kPartial = 0x800000u, kBaseMask = 0xFFFFu, kLabelMask = 0x7Fu, kLabelShift = 16; // (dfa.h: DfaImage)
+constexpr uint32_t kArr = 0x80000000u, kPartial = 0x40000000u, kBaseMask = 0xFFFFu, kLabelMask = 0xFFu, kLabelShift = 16; // (dfa.h: DfaImage)
 constexpr uint32_t kEvNone = 0xFFFFFFFFu, kEvList = 0x80000000u;
 
 // One transition, as every path here takes it (the scan's loop in assembly does the same: tools/gen_dfa_asm.py).

@@ -7,10 +7,11 @@ of the kernel per instruction of a chain-step at 100 MB, whatever the instructio
 is written out instruction by instruction, the C chains of a lane interleaved (every row below is
 emitted once per chain, a result is only needed C rows later), and everything rare sits behind ONE
 compare and branch per chain-step:
-  * the state word's top byte is zero except for kArr (bit 31: the entry arrived on is a virtual one);
-    the state a lane takes after a miss, M = code * stride, gets the byte below it of the state left,
-    shifted down by one, as its top byte -- bit 30 = that state was partial, a miss LDS may not decide.
-    So "top byte > 0x3f" finds both kinds of lanes, and the block behind the branch sorts them out:
+  * the state word's top byte holds kArr (bit 31: the entry arrived on is a virtual one) and partial (bit 30);
+    the state a lane takes after a miss, M = code * stride, gets the top byte of the state left, shifted
+    left by one, as its top byte -- its sign = that state was partial, a miss LDS may not decide (kArr drops
+    out, and so does the mark one step later).  So the sign of the new state finds both kinds of lanes --
+    after a miss the one, after a hit the other -- and the block behind the branch sorts them out:
     the global array is asked (lane by lane with scalar loads when the lanes are few -- a vector
     load's wait would also wait for the stream's stores, about 3 us -- all at once otherwise), arrivals
     go to their stream or counter.  The block comes back to where it left.
@@ -21,16 +22,15 @@ compare and branch per chain-step:
     for the next piece (in issue order) counts on.
 The text is plain assembly; operands in %[...] are those of the asm statement in kernels_dfa.hip.
 
-One step of chain j, state word S (dfa.h: kArr | 0 : 7 | partial | label : 7 | LDS base : 16):
+One step of chain j, state word S (dfa.h: kArr | partial | 0 : 6 | label : 8 | LDS base : 16):
     T = S.base + code;  X = lds[T]                           (issued during the previous step)
-    M = code * stride, its top byte = S's byte 2 >> 1
+    M = code * stride, its top byte = S's top byte << 1
     miss = label(X) != code;  S' = miss ? M : X
     miss: S.base to the miss stream (the state left)
 Registers.  Chain j: v[40 + 12 j ..]: W0 W1 window (8 codes), N0 N1 next piece, Ta Xa / Tb Xb slot
 index and slot word of the even / odd steps, M, R rank / store offset (M R also the pair a global slot
 is loaded into), L label (then LDS address), Sb the state after the even steps (the operand S holds
-it after the odd ones).  v20 scratch, v32 stride, v33 0x3f, v34 1, v36 cold_base, v37 2,
-v38 0x40000000.  s[36 + 2 j ..] miss mask, s[44 + j] its count, s[48:49] lanes the global array
+it after the odd ones).  v20 scratch, v32 stride, v34 1, v36 cold_base, v37 2.  s[36 + 2 j ..] miss mask, s[44 + j] its count, s[48:49] lanes the global array
 decides, s[56:57] those of them under cold_base, s[64:69] s[72:75] scratch, s70 the next piece's
 number, s71 m0, s[78:79] lane 63.
 """
@@ -95,9 +95,9 @@ def gen(C, exp=()):
         r = [".Lrare%s:" % t2]
         if "NOSLOW" not in exp:
             r += [
-                "v_cmp_le_i32_e64 %s, v38, %s" % (SL, nxt(j, k)),        # a miss LDS may not decide: the row's copy in the global array (dfa.h)
-                "s_cmp_eq_u64 %s, 0" % SL,
-                "s_cbranch_scc1 .Lra%s" % t2,
+                "v_cmp_gt_i32_e64 %s, 0, %s" % (SL, nxt(j, k)),          # the sign of the new state ...
+                "s_and_b64 %s, %s, %s" % (SL, SL, m(j)),                 # ... after a miss: a miss LDS may not decide -- the row's copy in the global array (dfa.h)
+                "s_cbranch_scc0 .Lra%s" % t2,
                 "s_bcnt1_i32_b64 s64, %s" % SL,
                 "s_cmp_gt_u32 s64, 5",
                 "s_cbranch_scc1 .Lsv%s" % t2,
@@ -126,7 +126,7 @@ def gen(C, exp=()):
                 "s_lshl_b32 s69, s65, 3",
                 "s_load_dwordx2 s[72:73], %[slot], s69",
                 "s_waitcnt lgkmcnt(0)",
-                "s_bfe_u32 s69, s72, 0x70010",                            # its label
+                "s_bfe_u32 s69, s72, 0x80010",                            # its label
                 "s_cmp_lg_u32 s69, s68",
                 "s_cbranch_scc1 .Lsn%s" % t2,                             # a miss there too
                 "s_mov_b32 m0, s64",                                      # (writelane takes one SGPR: the lane comes from m0)
@@ -159,7 +159,7 @@ def gen(C, exp=()):
                 "v_lshlrev_b32 %s, 3, %s" % (v(j, X), v(j, "L")),
                 "global_load_dwordx2 v[%s:%s], %s, %%[slot]" % (v(j, "M")[1:], v(j, "R")[1:], v(j, X)),
                 "s_waitcnt vmcnt(0)",
-                "v_bfe_u32 v20, %s, 16, 7" % v(j, "M"),
+                "v_bfe_u32 v20, %s, 16, 8" % v(j, "M"),
                 "v_cmp_eq_u32_sdwa s[66:67], %s, v20 src0_sel:BYTE_%d src1_sel:DWORD" % (v(j, wn), sel),
                 "s_andn2_b64 %s, %s, s[66:67]" % (m(j), m(j)),            # a hit there is no miss
                 "s_andn2_b64 exec, %s, s[66:67]" % COLD,                  # still a miss, under cold_base: the state's own counter
@@ -183,8 +183,9 @@ def gen(C, exp=()):
             ]
         if "NOARR" not in exp:
             r += [
-                "v_cmp_gt_i32_e64 s[64:65], 0, %s" % nxt(j, k),             # arrivals on virtual entries ...
+                "v_cmp_gt_i32_e64 s[64:65], 0, %s" % nxt(j, k),             # the sign after a hit: an arrival on a virtual entry ...
                 "v_cmp_gt_u32_e64 s[66:67], %%[hot], %s" % v(j, T),         # ... of LDS (the others were counted above)
+                "s_andn2_b64 s[64:65], s[64:65], %s" % m(j),
                 "s_and_b64 exec, s[64:65], s[66:67]",
                 "v_mbcnt_lo_u32_b32 v20, exec_lo, 0",
                 "v_mbcnt_hi_u32_b32 v20, exec_hi, v20",
@@ -209,7 +210,7 @@ def gen(C, exp=()):
                             % (v(j, "M"), v(j, wn), sel))
             if mark:
                 for j in range(C):
-                    main.append("v_lshrrev_b32_sdwa %s, v34, %s dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2"
+                    main.append("v_lshlrev_b32_sdwa %s, v34, %s dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3"
                                 % (v(j, "M"), cur(j, k)))
 
         # (a mask written by a vector compare: two wait states before a vector instruction reads it; a register
@@ -218,10 +219,8 @@ def gen(C, exp=()):
         if not late:
             after_miss()
         main.append("s_waitcnt lgkmcnt(0)")
-        for j in range(C):
-            main.append("v_bfe_u32 %s, %s, 16, 7" % (v(j, "L"), v(j, X)))
-        for j in range(C):
-            main.append("v_cmp_ne_u32_sdwa %s, %s, %s src0_sel:BYTE_%d src1_sel:DWORD" % (m(j), v(j, wn), v(j, "L"), sel))
+        for j in range(C):  # (the label is byte 2 of the slot word)
+            main.append("v_cmp_ne_u32_sdwa %s, %s, %s src0_sel:BYTE_%d src1_sel:BYTE_2" % (m(j), v(j, wn), v(j, X), sel))
         if late:
             after_miss()
             if C == 1:
@@ -232,7 +231,7 @@ def gen(C, exp=()):
         if not ("NOSLOW" in exp and "NOARR" in exp):
             for j in range(C):
                 t2 = "%%=_%d_%d" % (k, j)
-                main.append("v_cmp_lt_u32_sdwa vcc, v33, %s src0_sel:DWORD src1_sel:BYTE_3" % nxt(j, k))
+                main.append("v_cmp_gt_i32_e64 vcc, 0, %s" % nxt(j, k))
                 main.append("s_cbranch_vccnz .Lrare%s" % t2)
                 main.append(".Lbr%s:" % t2)
                 rare += rare_block(j, k)
@@ -257,11 +256,9 @@ def gen(C, exp=()):
     # ---- the loop
     main += [
         "v_mov_b32 v32, %[stride]",
-        "v_mov_b32 v33, 0x3f",
         "v_mov_b32 v34, 1",
         "v_mov_b32 v36, %[coldb]",
         "v_mov_b32 v37, 2",
-        "v_mov_b32 v38, 0x40000000",
         "s_mov_b32 s78, 0",
         "s_mov_b32 s79, 0x80000000",
     ]
@@ -295,7 +292,7 @@ def gen(C, exp=()):
 
 
 def clobbers(C):
-    regs = ["v20", "v32", "v33", "v34", "v36", "v37", "v38"] + ["v%d" % r for r in range(40, 40 + 12 * C)]
+    regs = ["v20", "v32", "v34", "v36", "v37"] + ["v%d" % r for r in range(40, 40 + 12 * C)]
     regs += ["s%d" % r for r in range(36, 36 + 2 * C)] + ["s%d" % (44 + j) for j in range(C)]
     regs += ["s48", "s49", "s56", "s57"] + ["s%d" % r for r in range(64, 76)] + ["s78", "s79"]
     return regs + ["vcc", "scc", "memory"]
