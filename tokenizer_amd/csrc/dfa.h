@@ -20,9 +20,10 @@
 //     the depth-1 states' rows sit at base c * stride, so that state needs no read at all;
 //   * a byte c for which some state on f's chain does have a child gets a VIRTUAL slot in s's own
 //     row (flagged kArr) that leads to that child's row and stands for the tokens emitted on the way.
-// Token counts come from events, not from ids: the kernel logs the slot whose state it left by a miss
-// (ev_miss[slot] = every token of the chain) and the virtual slot it arrived on (ev_arr[slot]); the
-// histogram over slots is turned into counts[id] with these tables at the end of an evaluation.
+// Token counts come from events, not from ids: the kernel logs the key of the state it left by a miss
+// (the state's LDS base, or its global base for the states that share cold_base: ev_miss[key] = every
+// token of the chain) and the index of the virtual entry it arrived on (ev_arr[entry]); the histogram
+// over keys is turned into counts[id] with these tables at the end of an evaluation.
 // What LDS holds is chosen entry by entry (a sample of the corpus run through the automaton, and after
 // a plan's first evaluation the scan's own counters, say which entries are used): see DfaImage below.
 #pragma once

@@ -724,14 +724,10 @@ void launch_dfa_count(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, co
 		const uint32_t blocks = std::min<uint32_t>(std::min<uint32_t>((W.nranges + 1023) / 1024, 64), miss_blocks);
 		F = DfaFix{A, codes, W.range_bytes, W.nranges, W.entry, W.exit_a, W.exit_b, W.exit_tag, changed, epoch, out, total_index, blocks};
 	}
-	StreamDev Qa2 = Qa, Qm2 = Qm;
-	if (getenv("TOKSCORE_DBG_NOARRHIST")) Qa2.capacity_batches = 0; // (debugging: timing only)
-	if (getenv("TOKSCORE_DBG_NOMISSHIST")) Qm2.capacity_batches = 0;
-	if (getenv("TOKSCORE_DBG_NOFIX")) F.blocks = 0;
 	const uint32_t lds = (A.hot_slots + 64) * 4; // + a spare word per lane
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dfa_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 	int16_t *rows = reinterpret_cast<int16_t *>(slab);
-	hipLaunchKernelGGL(dfa_hist_kernel, dim3(miss_blocks + arrival_blocks), dim3(1024), lds, stream, A, Qm2, Qa2, rows, miss_blocks, F, out,
+	hipLaunchKernelGGL(dfa_hist_kernel, dim3(miss_blocks + arrival_blocks), dim3(1024), lds, stream, A, Qm, Qa, rows, miss_blocks, F, out,
 	                   total_index);
 	const uint32_t colgroups = (A.hot_slots + 127) / 128;
 	const uint32_t ncold = A.nslots - A.hot_slots;
