@@ -277,6 +277,16 @@ int tokscore_hosttrie_longest(tokscore_ctx *ctx, const uint8_t *text, uint64_t n
 int tokscore_hostdfa_check(tokscore_ctx *ctx, const uint8_t *bytes, const uint64_t *off, uint64_t D, uint64_t max_slots,
                            uint32_t lds_slots, uint64_t *counts, uint64_t *total_tokens, uint64_t stats[8]);
 
+/* Host-side self-check of the search automaton tokscore_score_toggles builds for a batch of strings
+ * (tokenizer_amd/csrc/dfa.h: BuildSearchImage; no GPU, no context): strings k = codes[off[k] .. off[k+1])
+ * over the alphabet 1 .. ncodes-1, run over text[0 .. text_n) as the search kernel steps it.  Writes up
+ * to cap (string, position of its first byte) pairs in the order found, *n_found = all there were;
+ * stats (may be NULL): LDS slots, states, entries.  TOKSCORE_E_CAPACITY when the automaton does not
+ * fit max_slots.  Never used by any scoring entry point. */
+int tokscore_hostsearch_check(const uint8_t *codes, const uint32_t *off, uint32_t n, uint32_t ncodes, uint32_t max_slots,
+                              const uint8_t *text, uint64_t text_n, uint64_t *pairs, uint64_t cap, uint64_t *n_found,
+                              uint64_t stats[3]);
+
 /* Contexts without a GPU, for the host-side checks above only: set_vocab and
  * hosttrie_longest work, every scoring call fails with TOKSCORE_E_NO_DEVICE. */
 int tokscore_create_hostonly(tokscore_ctx **out);

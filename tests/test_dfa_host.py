@@ -71,3 +71,53 @@ def test_automaton_refuses_what_it_cannot_hold():
         s.hostdfa_check(corpus, off, max_slots=20_000)
     assert e.value.status == ta.E_VOCAB
     s.close()
+
+
+# ---- the search automaton of a batch of strings (tokscore_score_toggles' one-pass search) ----
+def _brute_occurrences(strings, text):
+    tb = text.tobytes()
+    found = set()
+    for k, s in enumerate(strings):
+        if len(s) < 2:
+            continue
+        i = tb.find(s)
+        while i >= 0:
+            found.add((k, i))
+            i = tb.find(s, i + 1)
+    return found
+
+
+@pytest.mark.parametrize("seed,ncodes,nstr,alphabet", [(1, 50, 64, 6), (2, 12, 200, 3), (3, 254, 64, 40), (4, 5, 30, 2)])
+def test_search_automaton_finds_every_occurrence(seed, ncodes, nstr, alphabet):
+    """Aho-Corasick in the scan's LDS-array layout (dfa.h: BuildSearchImage), stepped on the host as the
+    kernel steps it, against str.find: overlapping strings, strings that are suffixes / prefixes of each
+    other, duplicates, one-code strings (left out by contract), separators in the text."""
+    rng = np.random.default_rng(seed)
+    text = rng.integers(1, min(ncodes, alphabet + 1), size=20_000).astype(np.uint8)
+    text[rng.integers(0, len(text), size=200)] = 0  # document separators
+    strings = []
+    for _ in range(nstr):
+        if rng.random() < 0.5:  # drawn from the text: occurs
+            L = int(rng.integers(1, 9))
+            at = int(rng.integers(0, len(text) - L))
+            s = text[at:at + L].tobytes()
+            if 0 in s:
+                s = s.replace(b"\x00", b"\x01")
+        else:
+            s = rng.integers(1, min(ncodes, alphabet + 1), size=int(rng.integers(1, 7))).astype(np.uint8).tobytes()
+        strings.append(s)
+    strings.append(strings[0])  # a duplicate: both are reported
+    strings.append(strings[1][:1] + strings[1])  # an extension to the left: the shorter one ends where it ends
+    pairs, (slots, states, entries) = ta.hostsearch_check(strings, ncodes, text)
+    got = set(map(tuple, pairs.tolist()))
+    assert len(got) == len(pairs)  # nothing twice
+    assert got == _brute_occurrences(strings, text)
+    assert slots <= 40832 and states >= 1
+
+
+def test_search_automaton_that_does_not_fit_is_refused():
+    rng = np.random.default_rng(9)
+    strings = [rng.integers(1, 200, size=12).astype(np.uint8).tobytes() for _ in range(400)]
+    with pytest.raises(ta.TokscoreError) as e:
+        ta.hostsearch_check(strings, 201, np.zeros(16, np.uint8), max_slots=4096)
+    assert e.value.status == ta.E_CAPACITY

@@ -67,6 +67,7 @@ _SIGNATURES = [
     ("tokscore_drain_timings", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     ("tokscore_set_timing", C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     ("tokscore_hosttrie_longest", C.c_int, [C.c_void_p, _u8p, C.c_uint64, _u64p, _u64p]),
+    ("tokscore_hostsearch_check", C.c_int, [_u8p, C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, _u8p, C.c_uint64, _u64p, C.c_uint64, _u64p, _u64p]),
     ("tokscore_hostdfa_check", C.c_int, [C.c_void_p, _u8p, _u64p, C.c_uint64, C.c_uint64, C.c_uint32, _u64p, _u64p, _u64p]),
     ("tokscore_probe_read_bandwidth", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(C.c_double)]),
 ]
@@ -108,6 +109,32 @@ def _p8(a):
 
 def _p64(a):
     return a.ctypes.data_as(_u64p)
+
+
+def hostsearch_check(strings, ncodes: int, text: np.ndarray, max_slots: int = 40832):
+    """Host self-check of the search automaton of a batch of strings (tokscore_hostsearch_check; no GPU):
+    strings = byte strings over the codes 1 .. ncodes - 1, text = uint8 codes.  -> (pairs[n, 2] of (string,
+    position of its first byte) in the order found, (LDS slots, states, entries))."""
+    lib = load_library()
+    codes = np.frombuffer(b"".join(strings), dtype=np.uint8).copy() if strings else np.zeros(0, np.uint8)
+    off = np.zeros(len(strings) + 1, dtype=np.uint32)
+    off[1:] = np.cumsum([len(x) for x in strings])
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    n_found = C.c_uint64(0)
+    stats = np.zeros(3, dtype=np.uint64)
+    cap = max(16, 4 * len(text))
+    buf = codes if len(codes) else np.zeros(1, np.uint8)
+    tbuf = text if len(text) else np.zeros(1, np.uint8)
+    while True:
+        pairs = np.zeros(2 * cap, dtype=np.uint64)
+        rc = lib.tokscore_hostsearch_check(_p8(buf), off.ctypes.data_as(C.POINTER(C.c_uint32)), len(strings), ncodes, max_slots,
+                                           _p8(tbuf), len(text), _p64(pairs), cap, C.byref(n_found), _p64(stats))
+        if rc != 0:
+            raise TokscoreError(rc, "hostsearch_check")
+        if n_found.value <= cap:
+            break
+        cap = n_found.value
+    return pairs[: 2 * n_found.value].reshape(-1, 2).astype(np.int64), tuple(int(x) for x in stats)
 
 
 class Scorer:

@@ -741,4 +741,172 @@ void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint
 		        (unsigned long long)kind[0], (unsigned long long)kind[1], (unsigned long long)kind[2], (unsigned long long)kind[3]);
 }
 
+// ---- the search automaton of a batch of strings (dfa.h) ----------------------------------------------
+bool BuildSearchImage(const uint8_t *codes, const uint32_t *off, uint32_t n, uint32_t ncodes, uint32_t max_slots, SearchImage *out) {
+	// (runs once per batch of moves, on the host, in front of the launches: flat arrays, no allocation per state)
+	*out = SearchImage{};
+	if (ncodes < 2 || ncodes > DfaImage::kMaxCodes || max_slots > DfaImage::kMaxHot || n >= 0x10000u) return false;
+	const uint32_t cap = off[n] + 1; // states: the root and at most one per byte of the strings
+	const uint32_t NC = ncodes;
+	std::vector<uint32_t> delta((size_t)cap * NC, 0); // first the children (0 = none: the root is nobody's child), then the full transition function
+	std::vector<uint32_t> parent(cap, 0), fail(cap, 0), depth(cap, 0), out_link(cap, 0), first_end(cap, 0xFFFFFFFFu), next_end(n, 0xFFFFFFFFu);
+	std::vector<uint8_t> code_of(cap, 0), is_child;
+	uint32_t S = 1, max_len = 0;
+	for (uint32_t k = 0; k < n; k++) {
+		const uint32_t len = off[k + 1] - off[k];
+		if (len < 2 || len > 0x7FFFu) continue;
+		bool ok = true;
+		for (uint32_t i = off[k]; i < off[k + 1]; i++)
+			if (codes[i] == 0 || codes[i] >= NC) ok = false;
+		if (!ok) continue; // (cannot occur in a prepared corpus)
+		uint32_t v = 0;
+		for (uint32_t i = off[k]; i < off[k + 1]; i++) {
+			const uint8_t c = codes[i];
+			uint32_t &to = delta[(size_t)v * NC + c];
+			if (!to) {
+				to = S;
+				parent[S] = v, code_of[S] = c, depth[S] = depth[v] + 1;
+				S++;
+			}
+			v = to;
+		}
+		next_end[k] = first_end[v]; // strings that end at v: a list through next_end
+		first_end[v] = k;
+		max_len = std::max(max_len, len);
+	}
+	// breadth first: fail links, then the transitions of a state without the child filled in from its fail state's
+	std::vector<uint32_t> order;
+	order.reserve(S);
+	is_child.assign((size_t)S * NC, 0);
+	for (uint32_t c = 0; c < NC; c++)
+		if (delta[c]) order.push_back(delta[c]), is_child[c] = 1;
+	for (size_t h = 0; h < order.size(); h++) {
+		const uint32_t v = order[h];
+		const uint32_t f = depth[v] == 1 ? 0u : delta[(size_t)fail[parent[v]] * NC + code_of[v]];
+		fail[v] = f;
+		out_link[v] = first_end[v] != 0xFFFFFFFFu ? v : out_link[f];
+		uint32_t *dv = &delta[(size_t)v * NC];
+		const uint32_t *df = &delta[(size_t)f * NC];
+		for (uint32_t c = 0; c < NC; c++) {
+			if (dv[c]) {
+				order.push_back(dv[c]);
+				is_child[(size_t)v * NC + c] = 1;
+			} else dv[c] = df[c];
+		}
+	}
+	// rows: the depth-1 state of code c at c * stride (empty where no string starts with c; row 0, the separator's, is
+	// the start state) -- the smallest stride at which their entries do not meet; the others first fit, every state
+	// a base of its own (a lookup from base b at code c can only take an entry of the row that starts at b)
+	std::vector<uint32_t> ent_off(S + 1, 0), ent_code; // per state: the codes that lead deeper than depth 1
+	ent_code.reserve((size_t)S * 4);
+	for (uint32_t v = 0; v < S; v++) {
+		ent_off[v] = (uint32_t)ent_code.size();
+		if (v != 0) { // (the root has no entries of its own: depth-1 targets are what a miss means)
+			const uint32_t *dv = &delta[(size_t)v * NC];
+			for (uint32_t c = 1; c < NC; c++)
+				if (depth[dv[c]] >= 2) ent_code.push_back(c);
+		}
+	}
+	ent_off[S] = (uint32_t)ent_code.size();
+	std::vector<uint32_t> base(S, 0);
+	std::vector<uint8_t> used_slot((size_t)max_slots + NC, 0), used_base((size_t)max_slots + NC, 0);
+	uint32_t stride = 0;
+	for (uint32_t st = 1; st <= NC && !stride; st++) {
+		if ((size_t)(NC - 1) * st + NC > max_slots) return false;
+		bool ok = true;
+		for (uint32_t c = 1; c < NC && ok; c++) {
+			const uint32_t v = delta[c];
+			if (!v || depth[v] != 1) continue;
+			for (uint32_t e = ent_off[v]; e < ent_off[v + 1]; e++) {
+				uint8_t &u = used_slot[(size_t)c * st + ent_code[e]];
+				if (u) {
+					ok = false;
+					break;
+				}
+				u = 1;
+			}
+		}
+		if (ok) stride = st;
+		else std::fill(used_slot.begin(), used_slot.begin() + (size_t)NC * st + NC, 0);
+	}
+	if (!stride) return false; // (never: at stride = ncodes the rows are disjoint)
+	for (uint32_t c = 0; c < NC; c++) used_base[(size_t)c * stride] = 1;
+	for (uint32_t c = 1; c < NC; c++)
+		if (delta[c]) base[delta[c]] = c * stride;
+	uint32_t top = (NC - 1) * stride + NC;
+	{
+		// (this runs in front of every batch's launches: a row with entries is tried from the place of the last one on,
+		// never from the array's begin again -- a few more slots, a tenth of the time; a row without entries only needs a
+		// base nobody has)
+		uint32_t from = 0, next = 0;
+		for (uint32_t v : order) {
+			if (depth[v] == 1) continue; // (placed above)
+			const bool has = ent_off[v] != ent_off[v + 1];
+			uint32_t b = has ? next : from;
+			for (;; b++) {
+				if (b + NC > max_slots) return false;
+				if (used_base[b]) continue;
+				bool fits = true;
+				for (uint32_t e = ent_off[v]; e < ent_off[v + 1]; e++)
+					if (used_slot[b + ent_code[e]]) {
+						fits = false;
+						break;
+					}
+				if (fits) break;
+			}
+			base[v] = b;
+			used_base[b] = 1;
+			for (uint32_t e = ent_off[v]; e < ent_off[v + 1]; e++) used_slot[b + ent_code[e]] = 1;
+			while (used_base[from]) from++;
+			if (has) next = b + 1;
+			top = std::max(top, b + NC);
+		}
+	}
+	if (top > max_slots) return false;
+	out->hot.assign(top, DfaImage::kEmptyWord);
+	out->out_first.assign(top, SearchImage::kNone);
+	std::vector<uint32_t> first_of(S, SearchImage::kNone); // a state's records, shared by the entries that lead to it
+	auto records_of = [&](uint32_t u) {
+		if (first_of[u] != SearchImage::kNone) return first_of[u];
+		first_of[u] = (uint32_t)out->out_list.size();
+		for (uint32_t w = out_link[u]; w != 0; w = out_link[fail[w]])
+			for (uint32_t k = first_end[w]; k != 0xFFFFFFFFu; k = next_end[k]) out->out_list.push_back(k | depth[w] << 16);
+		out->out_list.back() |= 0x80000000u;
+		return first_of[u];
+	};
+	for (uint32_t v = 1; v < S; v++) {
+		const uint32_t *dv = &delta[(size_t)v * NC];
+		for (uint32_t e = ent_off[v]; e < ent_off[v + 1]; e++) {
+			const uint32_t c = ent_code[e], u = dv[c], t = base[v] + c;
+			uint32_t w = c << 16 | base[u];
+			if (out_link[u] != 0) {
+				w |= DfaImage::kArr;
+				out->out_first[t] = records_of(u);
+			}
+			out->hot[t] = w;
+		}
+	}
+	out->entries = (uint32_t)ent_code.size();
+	out->hot_slots = top, out->stride = stride, out->max_len = max_len, out->states = S;
+	return true;
+}
+
+void SearchRun(const SearchImage &img, const uint8_t *text, uint64_t n, std::vector<std::pair<uint32_t, uint64_t>> *found) {
+	uint32_t S = 0; // (the start state: base 0)
+	for (uint64_t i = 0; i < n; i++) {
+		const uint32_t c = text[i], t = (S & DfaImage::kBaseMask) + c;
+		const uint32_t x = t < img.hot_slots ? img.hot[t] : DfaImage::kEmptyWord;
+		if (((x >> DfaImage::kLabelShift) & DfaImage::kLabelMask) == c) {
+			S = x;
+			if (x & DfaImage::kArr) {
+				for (uint32_t o = img.out_first[t];; o++) {
+					const uint32_t r = img.out_list[o];
+					found->emplace_back(r & 0xFFFFu, i + 1 - ((r >> 16) & 0x7FFFu));
+					if (r & 0x80000000u) break;
+				}
+			}
+		} else S = c * img.stride;
+	}
+}
+
 } // namespace tokscore

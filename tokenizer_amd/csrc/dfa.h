@@ -30,6 +30,7 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace tokscore {
@@ -119,6 +120,30 @@ struct DfaOptions {
 	const DfaImage *reuse = nullptr;
 	uint64_t vocab_tag = 0;
 };
+
+// ---- a batch of strings searched in one pass (tokscore_score_toggles) ------------------------------
+// The same LDS array and the same step (kernels_dfa.hip: dfa_search_kernel runs the scan's loop on it), another
+// automaton: Aho-Corasick over the batch's strings in the corpus' code space.  State = the longest suffix of the
+// text read that is a prefix of some string; the transition on c goes to the deepest such state for the text
+// plus c.  Flattened as the scoring image is: the states of depth 1 have their rows at c * stride, a miss means
+// "the depth-1 state of c" (its row is empty when no string starts with c: the root's behaviour), and every
+// transition to a state of depth >= 2 is an entry of its own in the row of the state it leaves -- a few thousand
+// for 64 strings, all of them in LDS, no partial rows, no global array.  An entry whose target has a string of the
+// batch as a suffix carries kArr: the scan then logs (entry, position of the byte), and out_first / out_list say
+// which strings end there.  Strings of one code cannot be found this way and are left out (found[k] = 0): a
+// one-byte string is never toggled as a token end (the root row is all token ends).
+struct SearchImage {
+	std::vector<uint32_t> hot;       // [hot_slots] DfaImage's word layout; the start state is word 0 (base 0, an empty row)
+	std::vector<uint32_t> out_first; // [hot_slots] by entry: index into out_list, kNone where nothing ends
+	std::vector<uint32_t> out_list;  // string k | bytes << 16 | 0x80000000 on the last of an entry's records
+	uint32_t hot_slots = 0, stride = 0, max_len = 0, states = 0, entries = 0;
+	static constexpr uint32_t kNone = 0xFFFFFFFFu;
+};
+// strings: codes[off[k] .. off[k + 1]) for k < n, no code 0 and none >= ncodes inside.  false: the automaton does not fit
+// max_slots (the caller searches another way).
+bool BuildSearchImage(const uint8_t *codes, const uint32_t *off, uint32_t n, uint32_t ncodes, uint32_t max_slots, SearchImage *out);
+// CPU check of an image: every (string, position of its first byte) it reports on `text` (codes), as the kernels do
+void SearchRun(const SearchImage &img, const uint8_t *text, uint64_t n, std::vector<std::pair<uint32_t, uint64_t>> *found);
 
 // Host-side check of an image (CPU tests of the builder; never used by a scoring entry point): runs
 // the automaton over documents exactly as the kernel does -- codes of the lower-cased bytes, a

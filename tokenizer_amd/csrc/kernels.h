@@ -122,8 +122,11 @@ struct StreamWork {
 	unsigned long long *tg_starts = nullptr; // [prep_total / 64 + 1] written with tg_base (zeroed by the caller): bit q = a token of the vocabulary as it is starts at q
 	const uint32_t *tg_count = nullptr; // [kToggleLists] items appended per list (may exceed tg_cap: the surplus was not stored)
 	uint32_t tg_cap = 0;                // per list
+	const uint32_t *tg_index = nullptr; // optional: list entry -> item (the lists then hold indices into tg_items, tg_n)
+	const uint32_t *tg_n = nullptr;     // optional, by item: the item's n (above kToggleOffsets: the whole stream), instead of ToggleItem::n
 	const uint32_t *tg_slot = nullptr;  // [moves] the slot whose token-end bit the move flips
 	unsigned long long *tg_delta = nullptr; // [moves] tokens with the move - tokens without, mod 2^64
+	uint32_t tg_moves = 0;              // optional: moves of the batch (the local walks then add up per workgroup first)
 };
 constexpr uint32_t kToggleLists = 64; // the items of a batch are kept in this many lists, one per lane of the walk
 // One batch of independent moves (tokscore_score_toggles).  All pointers are device memory.
@@ -254,6 +257,37 @@ struct DfaScanPlan {
 	uint32_t lds_slots, lds_bytes;
 	uint32_t range_bytes, nwb;
 };
+// ---- one-pass search of a batch of strings (tokscore_score_toggles; dfa.h: SearchImage) ----
+struct SearchDev {
+	const uint32_t *hot;       // [hot_slots, padded to 16 bytes] the search automaton's LDS array
+	const uint32_t *out_first; // [hot_slots] by entry: first record of out_list (0xFFFFFFFF: none)
+	const uint32_t *out_list;  // string | bytes << 16 | 0x80000000 on an entry's last record
+	uint32_t hot_slots, stride, max_len;
+};
+// (string, stream) -> item, open addressing; what launch_local_toggles / launch_walk_toggles then read as
+// the kToggleLists lists list_index (StreamWork::tg_index; tg_n = count: an item's n)
+struct SearchItems {
+	unsigned long long *keys;  // [slots] 0 = free, else (string << 32 | stream) + 1
+	uint32_t *count;           // [slots] occurrences on a token start seen for the key (zeroed by the caller, with keys)
+	ToggleItem *items;         // [slots] stream, move (= string), off[] filled here; n is `count`
+	uint32_t mask;             // slots - 1, slots a power of two
+	uint32_t *flags;           // [0] != 0: the table was full (the caller comes again with a larger one)
+	uint32_t *list_index;      // [kToggleLists][list_cap] the slots in use, in the order they were claimed: what the walks read
+	uint32_t *list_count;      // [kToggleLists] slots listed (may exceed list_cap: the surplus was not stored; zeroed by the caller)
+	uint32_t list_cap;
+	const unsigned long long *starts; // bit q: a token of the vocabulary as it is starts at prepared offset q
+	const uint32_t *pbeg;      // [nstreams + 1] stream boundaries (prepared offsets)
+	const uint32_t *block_stream; // [prep_total / 256 + 1] the stream that holds prepared offset 256 b
+	uint32_t nstreams;
+};
+// block_stream from pbeg (once per plan)
+void launch_stream_blocks(const uint32_t *pbeg, uint32_t nstreams, uint32_t prep_total, uint32_t *block_stream, hipStream_t stream);
+// The automaton over all ranges of W.tcodes, every range from the start state and on over the first max_len - 1 bytes
+// of the next (from `codes`, the linear prepared corpus): records (entry | bytes behind the boundary << 16, position of
+// the string's last byte) go to Q (8 bytes each, Q.cursor[0] preset to the grid's waves, Q.cursor[1] = 0);
+// launch_search_items turns them into items.
+void launch_dfa_search(const SearchDev &A, const DfaWork &W, const StreamDev &Q, const uint8_t *codes, const DfaScanPlan &plan, hipStream_t stream);
+void launch_search_items(const SearchDev &A, const StreamDev &Q, const SearchItems &H, uint32_t num_cus, hipStream_t stream);
 // dfa_lds_slots_max(lds_cap): slots of the LDS array; lds_cap = 0, or fewer than fit (tests: most lookups
 // and events then go the way of the global array)
 bool plan_dfa_scan(uint32_t hot_slots, uint64_t prep_total, uint32_t num_cus, uint32_t chains_hint, DfaScanPlan *plan);

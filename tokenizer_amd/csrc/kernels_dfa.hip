@@ -313,6 +313,202 @@ __global__ void __launch_bounds__(1024) dfa_scan_asm_kernel(DfaDev A, DfaWork W,
 	la.close(Qa, lane);
 }
 
+// ---- one-pass search of a batch of strings (tokscore_score_toggles) -----------------------------------
+// The scan's loop on the search automaton of dfa.h (BuildSearchImage): every range starts in the start
+// state, nothing is logged but arrivals -- (entry, prepared offset of the byte) in 8 bytes -- and there is
+// no global array.  A string that crosses a range boundary is not seen here: search_items_kernel's last
+// workgroups read those few bytes again.
+template <int C>
+__global__ void __launch_bounds__(1024) dfa_search_kernel(SearchDev A, DfaWork W, StreamDev Qa, const uint8_t *codes) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t dfa_search_smem[];
+	LDS_AS uint32_t *img = (LDS_AS uint32_t *)dfa_search_smem;
+	{
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(A.hot);
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)img;
+		for (uint32_t i = threadIdx.x; i < (A.hot_slots + 3) / 4; i += blockDim.x) dst[i] = src[i];
+	}
+	__syncthreads();
+	if ((uint32_t)(uintptr_t)img != 0) { // (as dfa_scan_asm_kernel: the loop takes 4 * slot index for an LDS address)
+		if (threadIdx.x == 0) Qa.cursor[1] = 1u;
+		return;
+	}
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = uni32(threadIdx.x >> 6);
+	const uint32_t waves = blockDim.x >> 6;
+	const uint32_t wave_id = blockIdx.x * waves + wave;
+	const uint32_t total_waves = gridDim.x * waves;
+	EventLog la;
+	la.open_own(Qa, wave_id);
+	const uint32_t pieces = uni32(W.range_bytes / 8);
+	const uint32_t stride = A.stride;
+	// (a record is 8 bytes: a piece's steps add at most 8 * C * 64 of them)
+	constexpr uint32_t kHighBytes = kDfaBatchEntries * 2 - 8 * C * 64 * 8;
+	static_assert(kDfaBatchEntries * 2 >= 2 * 8 * C * 64 * 8, "a batch holds two pieces of records at least");
+	for (uint32_t wb = wave_id; wb < W.nwb; wb += total_waves) {
+		uint32_t S[4] = {0, 0, 0, 0}, G[4] = {0, 0, 0, 0}, P[4] = {0, 0, 0, 0};
+#pragma unroll
+		for (int j = 0; j < C; j++) P[j] = ((wb * C + j) * 64 + lane) * W.range_bytes; // (the prepared corpus is below 4 GiB)
+		const unsigned long long src = uni64((unsigned long long)(uintptr_t)(W.tcodes + (size_t)wb * pieces * C * 64));
+		uint32_t p = 0;
+		while (p < pieces) {
+			uint32_t voff = lane * 8 + p * (C * 512);
+			uint32_t curm = 0, cura = uni32(la.cur * 2);
+			const unsigned long long basea = uni64((unsigned long long)(uintptr_t)la.base);
+			uint32_t pp = uni32(p);
+#define DFA_SEARCH_OPERANDS                                                                                                  \
+	[p] "+s"(pp), [curm] "+s"(curm), [cura] "+s"(cura), [voff] "+v"(voff), [S0] "+v"(S[0]), [G0] "+v"(G[0]), [S1] "+v"(S[1]),         \
+	    [G1] "+v"(G[1]), [S2] "+v"(S[2]), [G2] "+v"(G[2]), [S3] "+v"(S[3]), [G3] "+v"(G[3])                                           \
+	    : [src] "s"(src), [pieces] "s"(pieces), [high] "s"(kHighBytes), [basea] "s"(basea), [stride] "v"(stride), [coldb] "v"(0xFFFFu), \
+	      [P0] "v"(P[0]), [P1] "v"(P[1]), [P2] "v"(P[2]), [P3] "v"(P[3])
+			if constexpr (C == 1) {
+				asm volatile(DFA_GEN_SEARCH1 : DFA_SEARCH_OPERANDS : DFA_GEN_CLOBBERS1);
+			} else if constexpr (C == 2) {
+				asm volatile(DFA_GEN_SEARCH2 : DFA_SEARCH_OPERANDS : DFA_GEN_CLOBBERS2);
+			} else {
+				asm volatile(DFA_GEN_SEARCH4 : DFA_SEARCH_OPERANDS : DFA_GEN_CLOBBERS4);
+			}
+#undef DFA_SEARCH_OPERANDS
+			p = pp;
+			la.cur = cura / 2;
+			if (la.cur * 2 > kHighBytes) la.roll(Qa, lane);
+		}
+		// the strings that begin in a range and end in the next: every lane goes on from the state it ended in, over
+		// the next range's first max_len - 1 bytes (from the linear copy), and logs the arrivals with how far behind
+		// the boundary they are -- whoever reads the record keeps the strings longer than that
+		if (A.max_len >= 2) {
+			const uint32_t reach = uni32(A.max_len - 1);
+#pragma unroll
+			for (int j = 0; j < C; j++) {
+				const uint2 *next = reinterpret_cast<const uint2 *>(codes + (size_t)P[j] + W.range_bytes); // (8-byte aligned; reads as separators behind the corpus)
+				uint32_t Sj = S[j];
+				uint2 w = next[0];
+				for (uint32_t i = 0; i < reach; i++) {
+					if (i != 0 && (i & 7u) == 0) w = next[i >> 3];
+					const uint32_t c = ((i & 4u ? w.y : w.x) >> (8 * (i & 3u))) & 0xFFu, t = (Sj & kBaseMask) + c;
+					const uint32_t x = img[t];
+					const bool hit = ((x >> kLabelShift) & kLabelMask) == c;
+					Sj = hit ? x : c * stride;
+					const bool arr = hit && (x & kArr) != 0;
+					const unsigned long long m = __builtin_amdgcn_ballot_w64(arr);
+					if (m != 0) {
+						if (arr) {
+							const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+							reinterpret_cast<uint2 *>(la.base)[la.cur / 4 + rank] = uint2{t | (i + 1) << 16, P[j] + W.range_bytes + i};
+						}
+						la.cur += 4 * (uint32_t)__builtin_popcountll(m);
+						if (la.cur * 2 > kHighBytes) la.roll(Qa, lane);
+					}
+				}
+			}
+		}
+	}
+	la.close(Qa, lane);
+}
+
+// (string, stream) -> the table's slot for it, claimed on first use.  Returns the slot when this call claimed it.
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
+__device__ __forceinline__ uint32_t search_emit(const SearchItems &H, uint32_t string, uint32_t q) {
+	if (!((H.starts[q >> 6] >> (q & 63)) & 1ull)) return kNoSlot; // inside a token of the vocabulary as it is: nothing can part there
+	uint32_t l = H.block_stream[q >> 8];
+	while (l + 1 < H.nstreams && H.pbeg[l + 1] <= q) l++;
+	const uint32_t rel = q - H.pbeg[l];
+	const unsigned long long key = ((unsigned long long)string << 32 | l) + 1ull;
+	uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & H.mask;
+	uint32_t claimed = kNoSlot;
+	for (uint32_t tries = 0;; tries++) {
+		// (most keys are new: the exchange straight away, not a look first)
+		unsigned long long seen = atomicCAS(&H.keys[h], 0ull, key);
+		if (seen == 0) {
+			H.items[h].stream = l, H.items[h].move = string;
+			claimed = h;
+			seen = key;
+		}
+		if (seen == key) break;
+		h = (h + 1) & H.mask;
+		if (tries > 256) { // (the caller sizes the table at four slots per item and more)
+			H.flags[0] = 1u;
+			return kNoSlot;
+		}
+	}
+	const uint32_t k = rel < 0xFFFFu ? atomicAdd(&H.count[h], 1u) : atomicAdd(&H.count[h], 1000u);
+	if (k < kToggleOffsets) H.items[h].off[k] = (uint16_t)rel;
+	return claimed;
+}
+__device__ __forceinline__ void search_list(const SearchItems &H, uint32_t q, uint32_t slot) {
+	const uint32_t at = atomicAdd(&H.list_count[q], 1u);
+	if (at < H.list_cap) H.list_index[(size_t)q * H.list_cap + at] = slot;
+}
+
+// every string that ends on `last_byte` and starts below `below`; returns one of the slots claimed (kNoSlot: none), any others are listed here
+__device__ __forceinline__ uint32_t search_emit_all(const SearchDev &A, const SearchItems &H, uint32_t entry, uint32_t last_byte, uint32_t below,
+                                                    uint32_t list) {
+	uint32_t claimed = kNoSlot;
+	for (uint32_t o = A.out_first[entry]; o != 0xFFFFFFFFu; o++) {
+		const uint32_t r = A.out_list[o];
+		const uint32_t first = last_byte + 1 - ((r >> 16) & 0x7FFFu);
+		if (first < below) {
+			const uint32_t c = search_emit(H, r & 0xFFFFu, first);
+			if (c != kNoSlot) {
+				if (claimed != kNoSlot) search_list(H, list, claimed);
+				claimed = c;
+			}
+		}
+		if (r & 0x80000000u) break;
+	}
+	return claimed;
+}
+
+// The search's records, a batch per wave at a time, into (string, stream) items.  New items are listed wave by wave
+// (one atomic per wave and round on one of kToggleLists counters: a single address takes about 90 atomics per
+// microsecond).
+__global__ void __launch_bounds__(256) search_items_kernel(SearchDev A, StreamDev Q, SearchItems H) {
+	const uint32_t record_blocks = gridDim.x;
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t my_list = (blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) % kToggleLists;
+	{
+		// a batch per workgroup at a time, its waves side by side: a record is a dozen dependent reads and atomics, so
+		// what counts is how many are under way
+		uint32_t batches = Q.cursor[0];
+		if (batches > Q.capacity_batches) batches = Q.capacity_batches;
+		const uint2 *rec = reinterpret_cast<const uint2 *>(Q.blocks);
+		for (uint32_t bt = blockIdx.x; bt < batches; bt += record_blocks) {
+			uint32_t n = Q.fill[bt]; // 16-bit entries written
+			if (n > kDfaBatchEntries) n = kDfaBatchEntries;
+			n = uni32(n / 4);
+			for (uint32_t i0 = (threadIdx.x >> 6) * 64; i0 < n; i0 += blockDim.x) {
+				uint32_t claimed = kNoSlot;
+				if (i0 + lane < n) {
+					const uint2 r = rec[(size_t)bt * (kDfaBatchEntries / 4) + i0 + lane];
+					// (r.x >> 16: found that many bytes behind a range boundary, by the lane of the range before it: the
+					// strings that begin before the boundary are its own)
+					const uint32_t behind = r.x >> 16;
+					claimed = search_emit_all(A, H, r.x & 0xFFFFu, r.y, behind ? r.y + 1 - behind : 0xFFFFFFFFu, my_list);
+				}
+				const unsigned long long m = __builtin_amdgcn_ballot_w64(claimed != kNoSlot);
+				if (m != 0) {
+					uint32_t at = 0;
+					if (lane == (uint32_t)__builtin_ctzll(m)) at = atomicAdd(&H.list_count[my_list], (uint32_t)__builtin_popcountll(m));
+					at = __builtin_amdgcn_readlane((int)at, __builtin_ctzll(m));
+					at += __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+					if (claimed != kNoSlot && at < H.list_cap) H.list_index[(size_t)my_list * H.list_cap + at] = claimed;
+				}
+			}
+		}
+	}
+}
+__global__ void __launch_bounds__(256) stream_blocks_kernel(const uint32_t *pbeg, uint32_t nstreams, uint32_t nblocks, uint32_t *block_stream) {
+	for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nblocks; b += gridDim.x * blockDim.x) {
+		const uint32_t q = b << 8;
+		uint32_t l = 0, h = nstreams; // last stream with pbeg <= q (pbeg[0] = 0)
+		while (h - l > 1) {
+			const uint32_t mid = (l + h) >> 1;
+			if (pbeg[mid] <= q) l = mid;
+			else h = mid;
+		}
+		block_stream[b] = l;
+	}
+}
+
 // ---- events -> counts ------------------------------------------------------------------------
 __device__ __forceinline__ void book_event(const DfaDev &A, uint32_t ev, long long n, unsigned long long *out,
                                            uint32_t total_index) {
@@ -475,15 +671,27 @@ __global__ void __launch_bounds__(1024) dfa_hist_kernel(DfaDev A, StreamDev Qm, 
                                                         unsigned long long *out, uint32_t total_index) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char dfa_hist_smem[];
 	uint32_t *bins = reinterpret_cast<uint32_t *>(dfa_hist_smem);
+#ifdef DFA_EXP_HIST1 // (timing experiments of csrc/Makefile exp_dfa: parts left out, results wrong)
+	return;
+#endif
 	if (F.blocks != 0 && blockIdx.x < F.blocks) dfa_fixup_body(F);
+#ifdef DFA_EXP_HIST2
+	return;
+#endif
 	const bool arrivals = blockIdx.x >= split;
 	const StreamDev &Q = arrivals ? Qa : Qm;
 	const uint32_t nblk = arrivals ? gridDim.x - split : split, bidx = arrivals ? blockIdx.x - split : blockIdx.x;
 	const uint32_t width = A.hot_slots;
 	for (uint32_t i = threadIdx.x; i < width + 64; i += blockDim.x) bins[i] = 0;
 	__syncthreads();
+#ifdef DFA_EXP_HIST3
+	return;
+#endif
 	uint32_t batches = Q.cursor[0];
 	if (batches > Q.capacity_batches) batches = Q.capacity_batches;
+#ifdef DFA_EXP_HIST4
+	batches = 0;
+#endif
 	constexpr uint32_t vecs_per_block = 512 * 2 / 16; // 64: one 1 KiB row per block of a batch
 	constexpr int kRowsInFlight = 8;
 	const uint32_t lane = threadIdx.x & 63;
@@ -600,6 +808,9 @@ __global__ void __launch_bounds__(1024) dfa_reduce_kernel(DfaDev A, const int16_
                                                           uint32_t first_batches, uint32_t *changed, unsigned long long *out,
                                                           uint32_t total_index) {
 	__shared__ int part[kDfaReduceGroups][64][4];
+#ifdef DFA_EXP_RED1
+	if (blockIdx.x != 0 || threadIdx.x != 0) return;
+#endif
 	if (blockIdx.x == 0 && threadIdx.x == 0) { // (the histogram has read the cursors, the fix-up is done with its words)
 		if (Qa.cursor[1]) Qm.cursor[1] = 1u; // one overflow word for the host
 		Qm.cursor[0] = first_batches, Qa.cursor[0] = first_batches, Qa.cursor[1] = 0u;
@@ -734,6 +945,31 @@ void launch_dfa_count(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, co
 	const uint32_t coldblocks = std::min<uint32_t>((ncold + 1023) / 1024, 256);
 	hipLaunchKernelGGL(dfa_reduce_kernel, dim3(colgroups + coldblocks), dim3(64 * kDfaReduceGroups), 0, stream, A, rows, miss_blocks,
 	                   miss_blocks + arrival_blocks, colgroups, W.cold_miss, W.cold_arr, Qm, Qa, first_batches, changed, out, total_index);
+}
+
+void launch_stream_blocks(const uint32_t *pbeg, uint32_t nstreams, uint32_t prep_total, uint32_t *block_stream, hipStream_t stream) {
+	const uint32_t nblocks = prep_total / 256 + 1;
+	hipLaunchKernelGGL(stream_blocks_kernel, dim3(std::min<uint32_t>((nblocks + 255) / 256, 4096)), dim3(256), 0, stream, pbeg, nstreams, nblocks,
+	                   block_stream);
+}
+
+void launch_dfa_search(const SearchDev &A, const DfaWork &W, const StreamDev &Q, const uint8_t *codes, const DfaScanPlan &plan, hipStream_t stream) {
+	const uint32_t lds = ((A.hot_slots + 3) & ~3u) * 4;
+	auto go = [&](auto kernel) {
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), lds, stream, A, W, Q, codes);
+	};
+	switch (plan.chains) {
+	case 1: go(&dfa_search_kernel<1>); break;
+	case 2: go(&dfa_search_kernel<2>); break;
+	default: go(&dfa_search_kernel<4>); break;
+	}
+}
+
+void launch_search_items(const SearchDev &A, const StreamDev &Q, const SearchItems &H, uint32_t num_cus, hipStream_t stream) {
+	const uint32_t record_blocks = std::max<uint32_t>(1, num_cus * 16);
+	hipLaunchKernelGGL(search_items_kernel, dim3(record_blocks), dim3(256), 0, stream, A, Q, H);
+
 }
 
 bool plan_dfa_scan(uint32_t hot_slots, uint64_t prep_total, uint32_t num_cus, uint32_t chains_hint, DfaScanPlan *plan) {

@@ -576,8 +576,10 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 					const uint32_t q = f % kToggleLists, idx = f / kToggleLists;
 					have = idx < s_count[q];
 					if (have) {
-						const ToggleItem *it = &W.tg_items[(size_t)q * W.tg_cap + idx];
-						have = it->n == kToggleWhole; // (the others: local_toggles_kernel)
+						size_t at = (size_t)q * W.tg_cap + idx;
+						if (W.tg_index) at = W.tg_index[at];
+						const ToggleItem *it = &W.tg_items[at];
+						have = W.tg_n ? W.tg_n[at] > kToggleOffsets : it->n == kToggleWhole; // (the others: local_toggles_kernel)
 						strm = it->stream;
 						move = it->move;
 						if (have) flip_slot = W.tg_slot[move];
@@ -797,11 +799,16 @@ __global__ void __launch_bounds__(1024) count_streams_kernel(StreamTrieDev T, St
 // every chain).  What lies between is counted once: occurrences are taken in ascending order and
 // those the last walk has passed are skipped.  Bytes come straight from the prepared corpus in
 // global memory (the walks are too short for a ring), the trie image from LDS.
+// (win / win_at: kLocalWindow bytes of the prepared corpus from win_at on, in LDS: a walk's bytes are mostly there, and a
+// byte from global memory costs a round trip of its own on a chain of dependent lookups)
+constexpr uint32_t kLocalWindow = 48; // (at most: what LDS has left beside the trie image decides, launch_local_toggles)
 __device__ __forceinline__ uint32_t local_token(const LDS_AS uint8_t *l_lt, const LDS_AS uint16_t *l_base, const uint8_t *prep,
-                                                uint32_t pos, uint32_t flip_slot, uint32_t &counts) {
+                                                uint32_t pos, uint32_t flip_slot, uint32_t &counts, const LDS_AS uint8_t *win, uint32_t win_at,
+                                                uint32_t window) {
 	uint32_t nb = 0, d = 0, len = 1, slot = 0;
 	do {
-		const uint32_t c = prep[pos + d];
+		const uint32_t rel = pos + d - win_at;
+		const uint32_t c = rel < window ? win[rel] : prep[pos + d];
 		const uint32_t t = nb + c;
 		uint32_t x = l_lt[t] ^ c;
 		if (t == flip_slot) x ^= 0x80u;
@@ -814,9 +821,14 @@ __device__ __forceinline__ uint32_t local_token(const LDS_AS uint8_t *l_lt, cons
 	return pos + len;
 }
 
-__global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, StreamWork W) {
+constexpr uint32_t kLocalMoves = 1024;
+__global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, StreamWork W, uint32_t window) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char local_smem[];
 	__shared__ uint32_t s_count[kToggleLists];
+	__shared__ int s_delta[kLocalMoves];
+	const bool by_block = W.tg_moves != 0 && W.tg_moves <= kLocalMoves;
+	if (by_block)
+		for (uint32_t i = threadIdx.x; i < W.tg_moves; i += blockDim.x) s_delta[i] = 0;
 	LDS_AS unsigned char *lds = (LDS_AS unsigned char *)local_smem;
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
@@ -833,6 +845,7 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	__syncthreads();
 	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
 	const LDS_AS uint16_t *l_base = (const LDS_AS uint16_t *)(lds + label_bytes);
+	LDS_AS uint8_t *win = lds + label_bytes + info_bytes + threadIdx.x * window; // this lane's window of the corpus
 	uint32_t most = s_count[lane];
 	for (int o = 32; o > 0; o >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, o, 64));
 	const uint32_t total_lanes = gridDim.x * blockDim.x;
@@ -841,7 +854,13 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 		int d = 0;
 		uint32_t move = 0;
 		if (idx < s_count[lane]) {
-			const ToggleItem it = W.tg_items[(size_t)lane * W.tg_cap + idx];
+			size_t at = (size_t)lane * W.tg_cap + idx;
+			if (W.tg_index) at = W.tg_index[at]; // (items made from the one-pass search: the lists hold their places in a table ...
+			ToggleItem it = W.tg_items[at];
+			if (W.tg_n) { // ... and the count is kept beside them)
+				const uint32_t n = W.tg_n[at];
+				it.n = n > kToggleOffsets ? kToggleWhole : (uint16_t)n;
+			}
 			if (it.n != kToggleWhole && it.n != 0) {
 				move = it.move;
 				const uint32_t flip_slot = W.tg_slot[move];
@@ -854,16 +873,28 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 						if (k < it.n && it.off[k] >= cur && it.off[k] < best) best = it.off[k];
 					if (best == 0xFFFFFFFFu) break;
 					uint32_t na = 0, nb2 = 0;
-					uint32_t pa = local_token(l_lt, l_base, W.prep, beg + best, 0xFFFFFFFFu, na);
-					uint32_t pb = local_token(l_lt, l_base, W.prep, beg + best, flip_slot, nb2);
+					const uint32_t win_at = (beg + best) & ~15u;
+					{
+						const u32x4 *src = reinterpret_cast<const u32x4 *>(W.prep + win_at); // (the prepared corpus is padded)
+						LDS_AS u32x4 *dst = (LDS_AS u32x4 *)win;
+#pragma unroll
+						for (uint32_t k = 0; k < kLocalWindow / 16; k++)
+							if (k * 16 < window) dst[k] = src[k];
+					}
+					uint32_t pa = local_token(l_lt, l_base, W.prep, beg + best, 0xFFFFFFFFu, na, win, win_at, window);
+					uint32_t pb = local_token(l_lt, l_base, W.prep, beg + best, flip_slot, nb2, win, win_at, window);
 					while (pa != pb) {
-						if (pa < pb) pa = local_token(l_lt, l_base, W.prep, pa, 0xFFFFFFFFu, na);
-						else pb = local_token(l_lt, l_base, W.prep, pb, flip_slot, nb2);
+						if (pa < pb) pa = local_token(l_lt, l_base, W.prep, pa, 0xFFFFFFFFu, na, win, win_at, window);
+						else pb = local_token(l_lt, l_base, W.prep, pb, flip_slot, nb2, win, win_at, window);
 					}
 					d += (int)nb2 - (int)na;
 					cur = pa - beg;
 				}
 			}
+		}
+		if (by_block) { // (items in no order of moves: per workgroup first, in LDS)
+			if (d != 0) atomicAdd(&s_delta[move], d);
+			continue;
 		}
 		// one atomic per move and wave (neighbouring items mostly belong to one move)
 		unsigned long long pend = __builtin_amdgcn_ballot_w64(d != 0);
@@ -876,6 +907,11 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 			if (lane == leader) atomicAdd(&W.tg_delta[m0], (unsigned long long)(long long)sum);
 			pend &= ~__builtin_amdgcn_ballot_w64(mine);
 		}
+	}
+	if (by_block) {
+		__syncthreads();
+		for (uint32_t i = threadIdx.x; i < W.tg_moves; i += blockDim.x)
+			if (s_delta[i] != 0) atomicAdd(&W.tg_delta[i], (unsigned long long)(long long)s_delta[i]);
 	}
 }
 
@@ -2080,11 +2116,14 @@ void launch_count_streams(const StreamTrieDev &T, const StreamWork &W, const Str
 
 void launch_local_toggles(const StreamTrieDev &T, const StreamWork &W, uint32_t num_cus, uint64_t max_items, hipStream_t stream) {
 	if (max_items == 0) return;
-	const uint32_t lds_bytes = ((T.nslots + 15) & ~15u) + ((T.nslots * 2 + 15) & ~15u);
+	const uint32_t image = ((T.nslots + 15) & ~15u) + ((T.nslots * 2 + 15) & ~15u);
+	const uint32_t lds_total = 160 * 1024 - 6 * 1024; // (the kernel's static arrays and slack)
+	const uint32_t window = image >= lds_total ? 0u : std::min<uint32_t>(kLocalWindow, ((lds_total - image) / 1024) & ~15u);
+	const uint32_t lds_bytes = image + 1024 * window;
 	const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(num_cus, (max_items + 1023) / 1024));
 	(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&local_toggles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
 	                          (int)lds_bytes);
-	hipLaunchKernelGGL(local_toggles_kernel, dim3(blocks), dim3(1024), lds_bytes, stream, T, W);
+	hipLaunchKernelGGL(local_toggles_kernel, dim3(blocks), dim3(1024), lds_bytes, stream, T, W, window);
 }
 
 void launch_walk_toggles(const StreamTrieDev &T, const StreamWork &W, const StreamScanPlan &plan, uint64_t max_items,

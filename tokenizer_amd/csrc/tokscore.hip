@@ -193,6 +193,15 @@ struct tokscore_ctx {
 	uint64_t knob_toggle_items = 32ull << 20; // (move, chunk) pairs one batch of moves may have
 	uint64_t tg_list_hint = 8192;             // entries per item list provided first (doubled when a batch needed more)
 	uint64_t toggle_items = 0; // (move, stream) items walked by score_toggles so far (diagnostics)
+	// ... by one pass of a search automaton over the corpus (kernels_dfa.hip: dfa_search_kernel) instead of the occurrence
+	// index and a search per (move, chunk): the (move, stream) table, the stream of every 256-byte block of the prepared corpus
+	bool knob_search = true;        // TOKSCORE_SEARCH=0: the index and per-chunk searches
+	uint64_t knob_search_moves = 256; // TOKSCORE_SEARCH_MOVES: moves per pass
+	unsigned char *d_sr_table = nullptr; // keys u64[slots] | count u32[slots] | items ToggleItem[slots]
+	size_t sr_table_bytes = 0;
+	uint64_t sr_slots_hint = 1u << 20;
+	uint32_t *d_block_stream = nullptr; // per stream plan
+	uint64_t search_batches = 0;    // batches judged this way (diagnostics)
 	// occurrence index (one bit per string and chunk), built by the first incremental re-score of a plan
 	uint32_t *d_index = nullptr;
 	int index_state = 0; // 0 not tried, 1 built, -1 not available (too large / allocation failed)
@@ -394,6 +403,8 @@ void free_plan(tokscore_ctx *c) {
 	if (c->d_slab) (void)hipFree(c->d_slab);
 	if (c->d_pbeg) (void)hipFree(c->d_pbeg);
 	c->d_pbeg = nullptr;
+	if (c->d_block_stream) (void)hipFree(c->d_block_stream);
+	c->d_block_stream = nullptr;
 	if (c->d_stream_order) (void)hipFree(c->d_stream_order);
 	c->d_stream_order = nullptr;
 	if (c->d_chunk_first) (void)hipFree(c->d_chunk_first);
@@ -1539,6 +1550,9 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	if (e != hipSuccess) return give_up("address of the library's static device scratch (is the gfx950 code object loaded?)", e);
 	c->knob_noincr = env_u64("TOKSCORE_NOINCR", 0) != 0;
 	c->knob_nobatch = env_u64("TOKSCORE_NOBATCH", 0) != 0;
+	c->knob_search = env_u64("TOKSCORE_SEARCH", 1) != 0;
+	c->knob_search_moves = std::min<uint64_t>(0xFFFF, std::max<uint64_t>(1, env_u64("TOKSCORE_SEARCH_MOVES", 256)));
+	c->sr_slots_hint = std::max<uint64_t>(1024, env_u64("TOKSCORE_SEARCH_SLOTS", 1u << 20));
 	c->knob_no_mark_ranges = env_u64("TOKSCORE_NOMARKRANGES", 0) != 0;
 	c->knob_incr_div = getenv("TOKSCORE_INCR_DIV") ? std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)) : 0;
 	c->knob_toggle_items = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 32ull << 20));
@@ -1597,6 +1611,7 @@ void tokscore_destroy(tokscore_ctx *c) {
 		if (c->d_tg_pairs) (void)hipFree(c->d_tg_pairs);
 		if (c->d_tg_items) (void)hipFree(c->d_tg_items);
 		if (c->d_tg_seen) (void)hipFree(c->d_tg_seen);
+		if (c->d_sr_table) (void)hipFree(c->d_sr_table);
 		if (c->h_tg_meta) (void)hipHostFree(c->h_tg_meta);
 		if (c->d_stream_tokens) (void)hipFree(c->d_stream_tokens);
 		if (c->d_tok_starts) (void)hipFree(c->d_tok_starts);
@@ -2006,6 +2021,144 @@ static int score_toggles_one_by_one(tokscore_ctx *c, const uint64_t *token_index
 	return st;
 }
 
+// One batch of tokscore_score_toggles by ONE pass over the corpus: the moves' strings as a search automaton
+// (dfa.h: BuildSearchImage) on the scan's loop and transposed corpus, its occurrences on token starts gathered
+// per (move, stream), then the walks of the other path.  1: not this way (no automaton plan for this corpus, the
+// batch's automaton does not fit LDS): the caller takes the occurrence index.  deltas -> res[0 .. n).
+int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s, int64_t *deltas);
+// (the pass over the corpus costs the same for any number of strings, the automaton must fit LDS: 256 moves at a time,
+// fewer where their automaton is too large)
+int score_toggles_by_search(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s, int64_t *deltas) {
+	uint32_t step = (uint32_t)std::max<uint64_t>(1, c->knob_search_moves);
+	for (uint32_t first = 0; first < n;) {
+		const uint32_t k = std::min(step, n - first);
+		const int st = search_batch(c, m + first, k, s, deltas + first);
+		if (st == 1 && first != 0 && k > 8) { // (the plan was there for the batches before: this one's automaton does not fit)
+			step = k / 2;
+			continue;
+		}
+		if (st) return st;
+		first += k;
+	}
+	return TOKSCORE_OK;
+}
+
+int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s, int64_t *deltas) {
+	if (!c->knob_search || n == 0 || n >= 0x10000u) return 1;
+	if (c->dfa_invalid) { // (as enqueue_score: the corpus or the trie changed since the automaton's plan was made)
+		(void)hipDeviceSynchronize();
+		free_dfa(c);
+		c->dfa_invalid = false;
+	}
+	ensure_dfa(c);
+	if (c->dfa_state != 1 || !c->d_dtcodes || !c->d_dstream_a) return 1;
+	// the strings in the automaton's codes
+	std::vector<uint8_t> codes;
+	std::vector<uint32_t> off(n + 1, 0);
+	for (uint32_t k = 0; k < n; k++) {
+		for (uint64_t i = c->h_vocab_off[m[k].token]; i < c->h_vocab_off[m[k].token + 1]; i++) codes.push_back(c->dimg.code[c->h_vocab_bytes[i]]);
+		off[k + 1] = (uint32_t)codes.size();
+	}
+	const bool trace = getenv("TOKSCORE_TRACE_HOST") != nullptr;
+	auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	const double t0 = now();
+	SearchImage img;
+	if (!BuildSearchImage(codes.data(), off.data(), n, c->dimg.ncodes, dfa_lds_slots_max(0), &img)) return 1;
+	const double t_img = now();
+	auto grow = [&](void **p, size_t *cap, size_t need) -> hipError_t {
+		if (need <= *cap) return hipSuccess;
+		if (*p) (void)hipFree(*p);
+		*p = nullptr, *cap = 0;
+		const hipError_t e = hipMalloc(p, need);
+		if (e == hipSuccess) *cap = need;
+		return e;
+	};
+	if (!c->d_block_stream) {
+		HIP_TRY(c, hipMalloc((void **)&c->d_block_stream, ((size_t)c->prep_total / 256 + 2) * sizeof(uint32_t)));
+		launch_stream_blocks(c->d_pbeg, c->nstreams, (uint32_t)c->prep_total, c->d_block_stream, s);
+	}
+	const DfaScanPlan &P = c->dplan;
+	const uint32_t first_batches = P.blocks * P.waves_per_block;
+	if (c->dstream_cap < first_batches + 16 || img.max_len > P.range_bytes) return 1; // (a string crosses one range boundary at most)
+	// blob (32-bit words): delta u64[n] | flags[2] | cursor[2] | list counts[kToggleLists] | slots[n] | hot | out_first | out_list
+	const size_t hot_words = ((size_t)img.hot_slots + 19) & ~(size_t)3; // (16 bytes of padding the kernel's 16-byte copies may read)
+	const size_t flags_at = 2 * (size_t)n, cursor_at = flags_at + 2, lists_at = cursor_at + 2, slots_at = lists_at + kToggleLists;
+	const size_t hot_at = (slots_at + n + 3) & ~(size_t)3, first_at = hot_at + hot_words, list_at = first_at + hot_words;
+	const size_t words = list_at + img.out_list.size() + 4;
+	for (;;) {
+		uint64_t slots = 1024;
+		while (slots < c->sr_slots_hint) slots <<= 1;
+		if (slots > (1ull << 28)) return 1;
+		const uint32_t list_cap = (uint32_t)(slots / 32); // (items <= slots / 2 in a table that is not full, spread evenly over the lists: four times their share)
+		const size_t table_bytes = slots * (sizeof(unsigned long long) + sizeof(uint32_t) + sizeof(ToggleItem)) + (size_t)kToggleLists * list_cap * sizeof(uint32_t);
+		HIP_TRY(c, grow((void **)&c->d_sr_table, &c->sr_table_bytes, table_bytes));
+		HIP_TRY(c, grow((void **)&c->d_tg_meta, &c->tg_meta_cap, words * sizeof(uint32_t)));
+		if (words * sizeof(uint32_t) > c->h_tg_meta_cap) {
+			if (c->h_tg_meta) (void)hipHostFree(c->h_tg_meta);
+			c->h_tg_meta = nullptr, c->h_tg_meta_cap = 0;
+			HIP_TRY(c, hipHostMalloc((void **)&c->h_tg_meta, words * sizeof(uint32_t) * 2, hipHostMallocDefault));
+			c->h_tg_meta_cap = words * sizeof(uint32_t) * 2;
+		}
+		uint32_t *h = reinterpret_cast<uint32_t *>(c->h_tg_meta);
+		memset(h, 0, hot_at * sizeof(uint32_t));
+		h[cursor_at] = first_batches;
+		for (uint32_t k = 0; k < n; k++) h[slots_at + k] = m[k].slot;
+		memcpy(h + hot_at, img.hot.data(), img.hot_slots * sizeof(uint32_t));
+		for (size_t i = img.hot_slots; i < hot_words; i++) h[hot_at + i] = DfaImage::kEmptyWord;
+		memcpy(h + first_at, img.out_first.data(), img.hot_slots * sizeof(uint32_t));
+		for (size_t i = img.hot_slots; i < hot_words; i++) h[first_at + i] = SearchImage::kNone;
+		if (!img.out_list.empty()) memcpy(h + list_at, img.out_list.data(), img.out_list.size() * sizeof(uint32_t));
+		HIP_TRY(c, hipMemcpyAsync(c->d_tg_meta, h, words * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+		uint32_t *d = reinterpret_cast<uint32_t *>(c->d_tg_meta);
+		unsigned long long *keys = reinterpret_cast<unsigned long long *>(c->d_sr_table);
+		uint32_t *count = reinterpret_cast<uint32_t *>(keys + slots);
+		ToggleItem *items = reinterpret_cast<ToggleItem *>(count + slots);
+		HIP_TRY(c, hipMemsetAsync(c->d_sr_table, 0, slots * (sizeof(unsigned long long) + sizeof(uint32_t)), s));
+		SearchDev A{d + hot_at, d + first_at, d + list_at, img.hot_slots, img.stride, img.max_len};
+		DfaWork Wd = dfa_work(c);
+		const StreamDev Q{c->d_dstream_a, c->dstream_cap, c->d_dfill_a, d + cursor_at};
+		uint32_t *list_index = reinterpret_cast<uint32_t *>(items + slots);
+		SearchItems H{keys, count, items, (uint32_t)(slots - 1), d + flags_at, list_index, d + lists_at, list_cap, c->d_tok_starts, c->d_pbeg, c->d_block_stream, c->nstreams};
+		launch_dfa_search(A, Wd, Q, c->d_dcodes, P, s);
+		launch_search_items(A, Q, H, (uint32_t)c->num_cus, s);
+		StreamWork W = stream_work(c, false);
+		W.tg_items = items;
+		W.tg_count = d + lists_at;
+		W.tg_cap = list_cap;
+		W.tg_index = list_index;
+		W.tg_n = count;
+		W.tg_moves = n;
+		W.tg_slot = d + slots_at;
+		W.tg_base = c->d_stream_tokens;
+		W.tg_delta = reinterpret_cast<unsigned long long *>(d);
+		launch_local_toggles(stream_trie_dev(c), W, (uint32_t)c->num_cus, (uint64_t)list_cap * kToggleLists, s);
+		launch_walk_toggles(stream_trie_dev(c), W, c->splan, (uint64_t)list_cap * kToggleLists, s);
+		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipMemcpyAsync(c->h_tg_meta, c->d_tg_meta, slots_at * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+		const double t_l = now();
+		HIP_TRY(c, hipStreamSynchronize(s));
+		if (trace)
+			fprintf(stderr, "score_toggles by search: automaton %.0f us (%u states, %u entries, %u slots), launches %.0f, wait %.0f\n", t_img - t0,
+			        img.states, img.entries, img.hot_slots, t_l - t_img, now() - t_l);
+		uint64_t made = 0;
+		uint32_t most = 0;
+		for (uint32_t q = 0; q < kToggleLists; q++) made += h[lists_at + q], most = std::max(most, h[lists_at + q]);
+		const bool full = h[flags_at] != 0 || most > list_cap;
+		const uint32_t overflow = h[cursor_at + 1];
+		if (overflow) return fail(c, TOKSCORE_E_CAPACITY, "search records overflow (internal capacity bound violated)");
+		if (made * 4 > slots) c->sr_slots_hint = std::max<uint64_t>(c->sr_slots_hint, made * 8); // (the next batch)
+		if (full) {
+			c->sr_slots_hint = std::max<uint64_t>(2 * slots, made * 8);
+			continue;
+		}
+		const uint64_t *res = reinterpret_cast<const uint64_t *>(c->h_tg_meta);
+		for (uint32_t k = 0; k < n; k++) deltas[k] = (int64_t)res[k];
+		c->toggle_items += made;
+		c->search_batches++;
+		return TOKSCORE_OK;
+	}
+}
+
 int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const int32_t *enable, uint64_t K,
                            int64_t *delta_total_tokens) {
 	if (!c || (K && (!token_index || !enable || !delta_total_tokens))) return fail(c, TOKSCORE_E_ARG, "null buffers");
@@ -2022,8 +2175,10 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 	if (st) return st;
 	bool batched = c->scan_path == 2 && c->chunks_synced && c->uniform_chunks && c->simg_valid &&
 	               !c->knob_noincr && !c->knob_nobatch;
-	if (batched && c->index_state == 0) build_index(c);
-	batched = batched && c->index_state == 1;
+	// (the occurrence index is only built when a batch cannot be searched in one pass: score_toggles_by_search)
+	bool by_search = batched && c->knob_search && c->dfa_enabled && c->dfa_state != -1;
+	if (batched && !by_search && c->index_state == 0) build_index(c);
+	batched = batched && (by_search || c->index_state == 1);
 	if (!batched) return score_toggles_one_by_one(c, token_index, enable, K, delta_total_tokens);
 	hipStream_t s = c->stream;
 	if (!c->pending.empty() || !c->pending_s.empty()) {
@@ -2041,11 +2196,22 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		delta_total_tokens[k] = 0;
 		bool flips = false;
 		const int64_t t = c->trie.PeekStream(token_index[k], enable[k] != 0, c->simg, &flips);
-		const int32_t row = c->tok_row[token_index[k]];
-		if (t < 0 || !flips || row < 0 || c->row_chunks[row] == 0) continue; // nothing in this corpus can change
-		moves.push_back(ToggleSpec{token_index[k], (uint32_t)row, (uint32_t)t, c->row_chunks[row]});
+		if (t < 0 || !flips) continue; // nothing can change
+		moves.push_back(ToggleSpec{token_index[k], 0u, (uint32_t)t, 0u});
 		move_k.push_back(k);
 	}
+	if (moves.empty()) return TOKSCORE_OK;
+	auto with_index_rows = [&]() { // the moves whose strings the corpus holds, with their rows of the occurrence index
+		size_t kept = 0;
+		for (size_t i = 0; i < moves.size(); i++) {
+			const int32_t row = c->tok_row[moves[i].token];
+			if (row < 0 || c->row_chunks[row] == 0) continue;
+			moves[kept] = ToggleSpec{moves[i].token, (uint32_t)row, moves[i].slot, c->row_chunks[row]};
+			move_k[kept++] = move_k[i];
+		}
+		moves.resize(kept), move_k.resize(kept);
+	};
+	if (!by_search) with_index_rows();
 	if (moves.empty()) return TOKSCORE_OK;
 	const double t_peek = now();
 	// tokens per stream under the vocabulary as it is: one walk over all streams, kept until the
@@ -2076,6 +2242,21 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		} else launch_count_streams(stream_trie_dev(c), Wb, c->splan, s);
 		HIP_TRY(c, hipGetLastError());
 		c->stream_tokens_epoch = c->trie_epoch;
+	}
+	if (by_search) {
+		std::vector<int64_t> d(moves.size());
+		st = score_toggles_by_search(c, moves.data(), (uint32_t)moves.size(), s, d.data());
+		if (st == TOKSCORE_OK) {
+			for (size_t i = 0; i < moves.size(); i++) delta_total_tokens[move_k[i]] = d[i];
+			if (trace) fprintf(stderr, "score_toggles: one-pass search, %zu moves, %.0f us\n", moves.size(), now() - t_begin);
+			return TOKSCORE_OK;
+		}
+		if (st != 1) return st;
+		// not this way: the occurrence index
+		if (c->index_state == 0) build_index(c);
+		if (c->index_state != 1) return score_toggles_one_by_one(c, token_index, enable, K, delta_total_tokens);
+		with_index_rows();
+		if (moves.empty()) return TOKSCORE_OK;
 	}
 	// (one launch addresses at most 2^32 - 16 (pair, stream) items: a batch never asks for more than that)
 	const uint64_t budget = std::max<uint64_t>(1, std::min<uint64_t>(c->knob_toggle_items, 0xFFFFFFF0ull / std::max<uint64_t>(1, c->widest_chunk) / 2));
@@ -2457,6 +2638,20 @@ int tokscore_hosttrie_longest(tokscore_ctx *c, const uint8_t *text, uint64_t n, 
 		c->device_trie_valid = false;
 	}
 	VocabTrie::Longest(c->packed, text, n, len, id);
+	return TOKSCORE_OK;
+}
+
+int tokscore_hostsearch_check(const uint8_t *codes, const uint32_t *off, uint32_t n, uint32_t ncodes, uint32_t max_slots,
+                              const uint8_t *text, uint64_t text_n, uint64_t *pairs, uint64_t cap, uint64_t *n_found,
+                              uint64_t stats[3]) {
+	if (!off || !n_found || (!codes && n && off[n]) || (!text && text_n) || (!pairs && cap)) return TOKSCORE_E_ARG;
+	SearchImage img;
+	if (!BuildSearchImage(codes, off, n, ncodes, max_slots, &img)) return TOKSCORE_E_CAPACITY;
+	std::vector<std::pair<uint32_t, uint64_t>> found;
+	SearchRun(img, text, text_n, &found);
+	*n_found = found.size();
+	for (uint64_t i = 0; i < found.size() && i < cap; i++) pairs[2 * i] = found[i].first, pairs[2 * i + 1] = found[i].second;
+	if (stats) stats[0] = img.hot_slots, stats[1] = img.states, stats[2] = img.entries;
 	return TOKSCORE_OK;
 }
 

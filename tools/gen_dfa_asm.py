@@ -195,6 +195,30 @@ def gen(C, exp=()):
                 "s_lshl1_add_u32 %[cura], s68, %[cura]",
                 "s_mov_b64 exec, -1",
             ]
+        if "SEARCH" in exp:
+            # the search automaton (dfa.h: BuildSearchDfa): no partial rows, no miss events; an arrival = some
+            # pattern ends at this byte: the entry arrived on and the byte's place in the prepared corpus
+            r = [".Lrare%s:" % t2,
+                 "v_cmp_gt_i32_e64 s[64:65], 0, %s" % nxt(j, k),
+                 "s_lshl_b32 s68, %[p], 3",
+                 "s_add_u32 s68, s68, %d" % k,
+                 # (loads and stores share one counter: the piece under way is waited for before the piece's first
+                 # store, so that the wait at the piece's end never waits for stores)
+                 "s_cmp_lg_u32 s77, 0",
+                 "s_cbranch_scc1 .Lsk%s" % t2,
+                 "s_waitcnt vmcnt(0)",
+                 "s_mov_b32 s77, 1",
+                 ".Lsk%s:" % t2,
+                 "s_mov_b64 exec, s[64:65]",
+                 "v_mbcnt_lo_u32_b32 v20, exec_lo, 0",
+                 "v_mbcnt_hi_u32_b32 v20, exec_hi, v20",
+                 "v_lshl_add_u32 v20, v20, 3, %[cura]",
+                 "v_mov_b32 %s, %s" % (v(j, "M"), v(j, T)),
+                 "v_add_u32 %s, s68, %%[P%d]" % (v(j, "R"), j),
+                 "global_store_dwordx2 v20, v[%s:%s], %%[basea]" % (v(j, "M")[1:], v(j, "R")[1:]),
+                 "s_bcnt1_i32_b64 s68, exec",
+                 "s_lshl3_add_u32 %[cura], s68, %[cura]",
+                 "s_mov_b64 exec, -1"]
         r.append("s_branch .Lbr%s" % t2)
         return r
 
@@ -202,7 +226,7 @@ def gen(C, exp=()):
         nonlocal main, rare
         wn, sel = wsel(k)
         T, X = ("Ta", "Xa") if k % 2 == 0 else ("Tb", "Xb")
-        mark = "NOSLOW" not in exp
+        mark = "NOSLOW" not in exp and "SEARCH" not in exp
 
         def after_miss():  # the state after a miss, marked where the state left is a partial one
             for j in range(C):
@@ -239,7 +263,7 @@ def gen(C, exp=()):
         if k < 7:
             issue(k + 1, lambda j: nxt(j, k))
         # ---- the states left by a miss: their base to the miss stream
-        if "NOLOG" not in exp:
+        if "NOLOG" not in exp and "SEARCH" not in exp:
             for j in range(C):
                 main.append("v_mbcnt_lo_u32_b32 %s, %s, 0" % (v(j, "R"), mlo(j)))
             for j in range(C):
@@ -261,6 +285,7 @@ def gen(C, exp=()):
         "v_mov_b32 v37, 2",
         "s_mov_b32 s78, 0",
         "s_mov_b32 s79, 0x80000000",
+        "s_mov_b32 s77, 0",
     ]
     for j in range(C):
         main.append("global_load_dwordx2 v[%s:%s], %%[voff], %%[src] offset:%d" % (v(j, "W0")[1:], v(j, "W1")[1:], 512 * j))
@@ -272,8 +297,11 @@ def gen(C, exp=()):
     issue(0, lambda j: "%%[S%d]" % j)
     for k in range(8):
         step(k)
-    stores = 0 if "NOLOG" in exp else 8 * C
-    main.append("s_waitcnt vmcnt(%d)" % stores)  # (in issue order: the piece came before the body's stores, one per step and chain)
+    stores = 0 if ("NOLOG" in exp or "SEARCH" in exp) else 8 * C
+    if "SEARCH" in exp:
+        main += ["s_cmp_lg_u32 s77, 0", "s_cbranch_scc1 .Lhave%=", "s_waitcnt vmcnt(0)", ".Lhave%=:", "s_mov_b32 s77, 0"]
+    else:
+        main.append("s_waitcnt vmcnt(%d)" % stores)  # (in issue order: the piece came before the body's stores, one per step and chain)
     for j in range(C):
         main.append("v_mov_b32 %s, %s" % (v(j, "W0"), v(j, "N0")))
         main.append("v_mov_b32 %s, %s" % (v(j, "W1"), v(j, "N1")))
@@ -294,7 +322,7 @@ def gen(C, exp=()):
 def clobbers(C):
     regs = ["v20", "v32", "v34", "v36", "v37"] + ["v%d" % r for r in range(40, 40 + 12 * C)]
     regs += ["s%d" % r for r in range(36, 36 + 2 * C)] + ["s%d" % (44 + j) for j in range(C)]
-    regs += ["s48", "s49", "s56", "s57"] + ["s%d" % r for r in range(64, 76)] + ["s78", "s79"]
+    regs += ["s48", "s49", "s56", "s57"] + ["s%d" % r for r in range(64, 76)] + ["s77", "s78", "s79"]
     return regs + ["vcc", "scc", "memory"]
 
 
@@ -320,6 +348,7 @@ def main():
             emit(f, "DFA_GEN_LOOP%d" % C, gen(C))
             f.write("#endif\n")
             f.write("#define DFA_GEN_CLOBBERS%d %s\n" % (C, ", ".join('"%s"' % r for r in clobbers(C))))
+            emit(f, "DFA_GEN_SEARCH%d" % C, gen(C, ("SEARCH",)))
     print("wrote", os.path.normpath(OUT))
 
 
