@@ -249,10 +249,17 @@ def moves_per_sec(scorer, tokens, corpus, off):
 
     # (iii) K = 64 independent moves judged by one tokscore_score_toggles call, none applied
     batches = [rng.choice(multi, size=64, replace=False) for _ in range(6)]
-    scorer.score_toggles(batches[0], 0)  # builds the occurrence index
+    scorer.score_toggles(batches[0], 0)  # (the first call's buffers; the occurrence index where the one-pass search does not serve)
     t0 = time.perf_counter()
     deltas = [scorer.score_toggles(b, 0) for b in batches[1:]]
     batched = 64 * len(deltas) / (time.perf_counter() - t0)
+    # ... and 256 per call: one pass of the search automaton over the corpus costs the same for any number of moves
+    big = [rng.choice(multi, size=256, replace=False) for _ in range(4)]
+    scorer.score_toggles(big[0], 0)
+    t0 = time.perf_counter()
+    big_deltas = [scorer.score_toggles(b, 0) for b in big[1:]]
+    batched256 = 256 * len(big_deltas) / (time.perf_counter() - t0)
+    search_passes = int(scorer.info().search_passes)
     base_tt = scorer.score(out=buf)[1]
     batched_exact = True
     for k in (0, 21, 42, 63):  # against two full evaluations
@@ -260,6 +267,11 @@ def moves_per_sec(scorer, tokens, corpus, off):
         tt = scorer.score(out=buf)[1]
         scorer.toggle(int(batches[1][k]), True)
         batched_exact = batched_exact and int(deltas[0][k]) == tt - base_tt
+    for k in (5, 250):
+        scorer.toggle(int(big[1][k]), False)
+        tt = scorer.score(out=buf)[1]
+        scorer.toggle(int(big[1][k]), True)
+        batched_exact = batched_exact and int(big_deltas[0][k]) == tt - base_tt
     scorer.score(out=buf)
     # (iv) the same call inside an annealing-like loop: 64 moves judged, the best one applied, the exact
     # score taken, again -- every call then starts from a changed vocabulary
@@ -291,7 +303,8 @@ def moves_per_sec(scorer, tokens, corpus, off):
     st = gen.Generate(0, threads=threads, seed=5)[-1]
     host = st.gen_cnt / (time.perf_counter() - t0)
     gen.close()
-    return {"gpu_score_toggles_k64": batched, "gpu_score_toggles_k64_exact": batched_exact,
+    return {"gpu_score_toggles_k64": batched, "gpu_score_toggles_k256": batched256, "gpu_score_toggles_exact": batched_exact,
+            "gpu_score_toggles_by": "one pass of a search automaton per 256 moves" if search_passes else "occurrence index + search per (move, chunk)",
             "gpu_anneal_like_loop_k64": anneal_like,
             "gpu_toggle_incremental_rescore": inc, "gpu_toggle_full_rescore": full,
             "host_dag_loop": host, "host_threads": threads, "host_candidates": n_cand,

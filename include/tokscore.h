@@ -229,7 +229,7 @@ typedef struct {
 	double dfa_plan_ms;         /* image + prepared corpus + buffers, once per corpus and vocabulary */
 	uint64_t dfa_second_hits;   /* lookups the L2 array answered with a hit, when the scan's counters were last read */
 	uint32_t dfa_relayouts;     /* times those counters were read to choose again what LDS holds (once per vocabulary state; TOKSCORE_DFA_RELAYOUTS) */
-	uint32_t dfa_reserved;
+	uint32_t search_passes;     /* passes of a search automaton over the corpus that tokscore_score_toggles has made (up to 256 moves each) */
 } tokscore_info;
 int tokscore_get_info(tokscore_ctx *ctx, tokscore_info *info);
 

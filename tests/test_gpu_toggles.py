@@ -31,13 +31,17 @@ def _check_moves(s, tokens, enabled, corpus, off, idx, en):
     return got
 
 
-@pytest.mark.parametrize("env", [{}, {"TOKSCORE_TOGGLE_ITEMS": "2000", "TOKSCORE_TOGGLE_LIST": "4"}, {"TOKSCORE_SCAN": "tile"},
-                                 {"TOKSCORE_NOMARKRANGES": "1"}])
+@pytest.mark.parametrize("env", [{}, {"TOKSCORE_SEARCH": "0"},
+                                 {"TOKSCORE_SEARCH": "0", "TOKSCORE_TOGGLE_ITEMS": "2000", "TOKSCORE_TOGGLE_LIST": "4"}, {"TOKSCORE_SCAN": "tile"},
+                                 {"TOKSCORE_NOMARKRANGES": "1"}, {"TOKSCORE_SEARCH_SLOTS": "1024"}, {"TOKSCORE_SEARCH_MOVES": "3"},
+                                 {"TOKSCORE_DFA_CHAINS": "1"}, {"TOKSCORE_DFA_CHAINS": "4"}])
 def test_deltas_equal_oracle_differences(env, monkeypatch):
-    """env: one batch / several batches (a small budget of pairs) whose item lists start too short and
-    have to be provided again / the move-by-move fallback on a scan path without the batched kernel /
-    token starts and tokens per stream always from the walk over streams (after a full evaluation they
-    come from its ranges otherwise)."""
+    """env: the moves' strings found by one pass of a search automaton over the corpus (the default where the
+    automaton scan has a plan) / through the occurrence index and a search per (move, chunk): one batch / several
+    batches (a small budget of pairs) whose item lists start too short and have to be provided again / the
+    move-by-move fallback on a scan path without the batched kernel / token starts and tokens per stream always
+    from the walk over streams (after a full evaluation they come from its ranges otherwise) / the search's
+    (move, stream) table too small at first / three moves per pass / the search loop for 1 and 4 ranges per lane."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     corpus, off = synth.wiki_like(1_500_000, seed=31)
@@ -65,6 +69,10 @@ def test_deltas_equal_oracle_differences(env, monkeypatch):
         assert got[3] == 0 and got[-1] == got[0]
         assert s.info().base_scan_path == (1 if env.get("TOKSCORE_SCAN") == "tile" else 2)
         assert (s.info().toggle_streams > 0) == (env.get("TOKSCORE_SCAN") != "tile"), "which path served the call"
+        by_search = env.get("TOKSCORE_SCAN") != "tile" and env.get("TOKSCORE_SEARCH") != "0"
+        assert (s.info().search_passes > 0) == by_search, "which path served the call"
+        if "TOKSCORE_SEARCH_MOVES" in env:
+            assert s.info().search_passes >= 4
         assert any(int(d) != 0 for d in got)
         # nothing was changed by asking
         again = s.score(incremental=True)
@@ -87,7 +95,13 @@ def test_deltas_equal_oracle_differences(env, monkeypatch):
         s.close()
 
 
-def test_deltas_on_cjk_and_many_moves():
+@pytest.mark.parametrize("forced", [False, True])
+def test_deltas_on_cjk_and_many_moves(forced, monkeypatch):
+    """forced: the automaton scan's plan although its policy would not take this vocabulary -- the moves then go
+    through the one-pass search (multi-byte code points, 100+ codes); otherwise through the occurrence index."""
+    if forced:
+        monkeypatch.setenv("TOKSCORE_DFA_MAX_COLD_PPM", "1000000")
+        monkeypatch.setenv("TOKSCORE_DFA_MAX_VIRTUAL_PPM", "1000000")
     corpus, off = synth.cjk_heavy(400_000, seed=9)
     tokens = synth.build_vocab(corpus[:200_000], 9000)
     V = len(tokens)
@@ -96,13 +110,13 @@ def test_deltas_on_cjk_and_many_moves():
         s.set_vocab(*synth.pack_vocab(tokens))
         s.set_corpus(corpus, off)
         base = s.score()
-        assert s.info().scan_path == 2
+        assert s.info().scan_path == 2 and s.info().dfa_active == (1 if forced else 0)
         enabled = np.ones(V, dtype=bool)
         rng = np.random.default_rng(11)
         multi = [i for i, t in enumerate(tokens) if len(t.decode("utf-8")) > 1]
         idx = [int(i) for i in rng.choice(multi, size=64, replace=False)]
         got = s.score_toggles(idx, 0)
-        assert s.info().toggle_streams > 0
+        assert s.info().toggle_streams > 0 and (s.info().search_passes > 0) == forced
         # the oracle on a sample of the 64, the rest through the scorer's own full evaluations
         for k in range(0, 64, 8):
             moved = enabled.copy()

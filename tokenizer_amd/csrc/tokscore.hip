@@ -2565,6 +2565,7 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 	info->rescored_chunks = c->rescored_chunks;
 	info->toggle_streams = c->toggle_items;
 	info->base_scan_path = info->scan_path;
+	info->search_passes = (uint32_t)std::min<uint64_t>(c->search_batches, 0xFFFFFFFFull);
 	if (c->dfa_state == 1 && !c->dfa_invalid) {
 		info->dfa_slots = c->dimg.nslots;
 		info->dfa_lds_slots = c->dimg.hot_slots;
