@@ -750,11 +750,12 @@ bool BuildSearchImage(const uint8_t *codes, const uint32_t *off, uint32_t n, uin
 	const uint32_t NC = ncodes;
 	std::vector<uint32_t> delta((size_t)cap * NC, 0); // first the children (0 = none: the root is nobody's child), then the full transition function
 	std::vector<uint32_t> parent(cap, 0), fail(cap, 0), depth(cap, 0), out_link(cap, 0), first_end(cap, 0xFFFFFFFFu), next_end(n, 0xFFFFFFFFu);
-	std::vector<uint8_t> code_of(cap, 0), is_child;
+	std::vector<uint32_t> first_child(cap, 0), next_sibling(cap, 0); // a state's children, a list through next_sibling
+	std::vector<uint8_t> code_of(cap, 0);
 	uint32_t S = 1, max_len = 0;
 	for (uint32_t k = 0; k < n; k++) {
 		const uint32_t len = off[k + 1] - off[k];
-		if (len < 2 || len > 0x7FFFu) continue;
+		if (len < 2 || len > 0x3FFFu) continue;
 		bool ok = true;
 		for (uint32_t i = off[k]; i < off[k + 1]; i++)
 			if (codes[i] == 0 || codes[i] >= NC) ok = false;
@@ -766,6 +767,7 @@ bool BuildSearchImage(const uint8_t *codes, const uint32_t *off, uint32_t n, uin
 			if (!to) {
 				to = S;
 				parent[S] = v, code_of[S] = c, depth[S] = depth[v] + 1;
+				next_sibling[S] = first_child[v], first_child[v] = S;
 				S++;
 			}
 			v = to;
@@ -774,90 +776,91 @@ bool BuildSearchImage(const uint8_t *codes, const uint32_t *off, uint32_t n, uin
 		first_end[v] = k;
 		max_len = std::max(max_len, len);
 	}
-	// breadth first: fail links, then the transitions of a state without the child filled in from its fail state's
+	// breadth first: fail links; a state's transitions are its fail state's with its own children on top (a row copied,
+	// the children written over it), and so is the set of codes that lead deeper than depth 1 -- its row's entries -- as a
+	// bit mask over the codes (four words: codes are bytes)
+	struct Mask {
+		uint64_t w[4];
+	};
+	std::vector<Mask> row(S, Mask{{0, 0, 0, 0}});
 	std::vector<uint32_t> order;
 	order.reserve(S);
-	is_child.assign((size_t)S * NC, 0);
-	for (uint32_t c = 0; c < NC; c++)
-		if (delta[c]) order.push_back(delta[c]), is_child[c] = 1;
+	for (uint32_t u = first_child[0]; u; u = next_sibling[u]) order.push_back(u);
 	for (size_t h = 0; h < order.size(); h++) {
 		const uint32_t v = order[h];
 		const uint32_t f = depth[v] == 1 ? 0u : delta[(size_t)fail[parent[v]] * NC + code_of[v]];
 		fail[v] = f;
 		out_link[v] = first_end[v] != 0xFFFFFFFFu ? v : out_link[f];
 		uint32_t *dv = &delta[(size_t)v * NC];
-		const uint32_t *df = &delta[(size_t)f * NC];
-		for (uint32_t c = 0; c < NC; c++) {
-			if (dv[c]) {
-				order.push_back(dv[c]);
-				is_child[(size_t)v * NC + c] = 1;
-			} else dv[c] = df[c];
+		// (v's own children sit in dv already: kept aside while the fail state's row is copied in)
+		memcpy(dv, &delta[(size_t)f * NC], NC * sizeof(uint32_t));
+		row[v] = row[f];
+		for (uint32_t u = first_child[v]; u; u = next_sibling[u]) {
+			dv[code_of[u]] = u;
+			row[v].w[code_of[u] >> 6] |= 1ull << (code_of[u] & 63);
+			order.push_back(u);
 		}
 	}
 	// rows: the depth-1 state of code c at c * stride (empty where no string starts with c; row 0, the separator's, is
-	// the start state) -- the smallest stride at which their entries do not meet; the others first fit, every state
-	// a base of its own (a lookup from base b at code c can only take an entry of the row that starts at b)
-	std::vector<uint32_t> ent_off(S + 1, 0), ent_code; // per state: the codes that lead deeper than depth 1
-	ent_code.reserve((size_t)S * 4);
-	for (uint32_t v = 0; v < S; v++) {
-		ent_off[v] = (uint32_t)ent_code.size();
-		if (v != 0) { // (the root has no entries of its own: depth-1 targets are what a miss means)
-			const uint32_t *dv = &delta[(size_t)v * NC];
-			for (uint32_t c = 1; c < NC; c++)
-				if (depth[dv[c]] >= 2) ent_code.push_back(c);
-		}
-	}
-	ent_off[S] = (uint32_t)ent_code.size();
+	// the start state) -- the smallest stride at which their entries do not meet; the others next fit, every state
+	// a base of its own (a lookup from base b at code c can only take an entry of the row that starts at b).  Slots and
+	// bases as bit sets: a place is tried with four shifted ANDs, whatever the row holds.
 	std::vector<uint32_t> base(S, 0);
-	std::vector<uint8_t> used_slot((size_t)max_slots + NC, 0), used_base((size_t)max_slots + NC, 0);
+	const size_t words = ((size_t)max_slots + NC) / 64 + 6;
+	std::vector<uint64_t> occ(words, 0), taken(words, 0); // slots in use, bases in use
+	auto window = [&](const std::vector<uint64_t> &bits, size_t at) { // 64 bits from bit `at` on
+		const size_t i = at >> 6, sh = at & 63;
+		return sh ? (bits[i] >> sh) | (bits[i + 1] << (64 - sh)) : bits[i];
+	};
+	auto fits = [&](uint32_t b, const Mask &m) {
+		for (int q = 0; q < 4; q++)
+			if (m.w[q] && (window(occ, (size_t)b + 64 * q) & m.w[q])) return false;
+		return true;
+	};
+	auto place = [&](uint32_t b, const Mask &m) {
+		for (int q = 0; q < 4; q++) {
+			if (!m.w[q]) continue;
+			const size_t at = (size_t)b + 64 * q, i = at >> 6, sh = at & 63;
+			occ[i] |= m.w[q] << sh;
+			if (sh) occ[i + 1] |= m.w[q] >> (64 - sh);
+		}
+		taken[b >> 6] |= 1ull << (b & 63);
+	};
 	uint32_t stride = 0;
 	for (uint32_t st = 1; st <= NC && !stride; st++) {
 		if ((size_t)(NC - 1) * st + NC > max_slots) return false;
 		bool ok = true;
-		for (uint32_t c = 1; c < NC && ok; c++) {
-			const uint32_t v = delta[c];
-			if (!v || depth[v] != 1) continue;
-			for (uint32_t e = ent_off[v]; e < ent_off[v + 1]; e++) {
-				uint8_t &u = used_slot[(size_t)c * st + ent_code[e]];
-				if (u) {
-					ok = false;
-					break;
-				}
-				u = 1;
-			}
+		for (uint32_t v = first_child[0]; v && ok; v = next_sibling[v]) {
+			if (!fits(code_of[v] * st, row[v])) ok = false;
+			else place(code_of[v] * st, row[v]);
 		}
 		if (ok) stride = st;
-		else std::fill(used_slot.begin(), used_slot.begin() + (size_t)NC * st + NC, 0);
+		std::fill(occ.begin(), occ.begin() + ((size_t)NC * st + NC) / 64 + 2, 0);
+		std::fill(taken.begin(), taken.begin() + ((size_t)NC * st + NC) / 64 + 2, 0);
 	}
 	if (!stride) return false; // (never: at stride = ncodes the rows are disjoint)
-	for (uint32_t c = 0; c < NC; c++) used_base[(size_t)c * stride] = 1;
-	for (uint32_t c = 1; c < NC; c++)
-		if (delta[c]) base[delta[c]] = c * stride;
+	for (uint32_t c = 0; c < NC; c++) {
+		const uint32_t v = c ? delta[c] : 0u; // (the root's row still holds its children only)
+		place(c * stride, v ? row[v] : Mask{{0, 0, 0, 0}}); // (a base of its own also where no string starts with c)
+		if (v) base[v] = c * stride;
+	}
 	uint32_t top = (NC - 1) * stride + NC;
 	{
-		// (this runs in front of every batch's launches: a row with entries is tried from the place of the last one on,
-		// never from the array's begin again -- a few more slots, a tenth of the time; a row without entries only needs a
-		// base nobody has)
+		// a row with entries is tried from the place of the last one on, never from the array's begin again (a few more
+		// slots, a tenth of the time); a row without entries only needs a base nobody has
 		uint32_t from = 0, next = 0;
 		for (uint32_t v : order) {
 			if (depth[v] == 1) continue; // (placed above)
-			const bool has = ent_off[v] != ent_off[v + 1];
+			const bool has = (row[v].w[0] | row[v].w[1] | row[v].w[2] | row[v].w[3]) != 0;
 			uint32_t b = has ? next : from;
 			for (;; b++) {
 				if (b + NC > max_slots) return false;
-				if (used_base[b]) continue;
-				bool fits = true;
-				for (uint32_t e = ent_off[v]; e < ent_off[v + 1]; e++)
-					if (used_slot[b + ent_code[e]]) {
-						fits = false;
-						break;
-					}
-				if (fits) break;
+				if ((taken[b >> 6] >> (b & 63)) & 1ull) continue;
+				if (!has || fits(b, row[v])) break;
 			}
 			base[v] = b;
-			used_base[b] = 1;
-			for (uint32_t e = ent_off[v]; e < ent_off[v + 1]; e++) used_slot[b + ent_code[e]] = 1;
-			while (used_base[from]) from++;
+			place(b, row[v]);
+			while ((taken[from >> 6] >> (from & 63)) & 1ull) from++;
 			if (has) next = b + 1;
 			top = std::max(top, b + NC);
 		}
@@ -874,19 +877,28 @@ bool BuildSearchImage(const uint8_t *codes, const uint32_t *off, uint32_t n, uin
 		out->out_list.back() |= 0x80000000u;
 		return first_of[u];
 	};
+	uint32_t entries = 0;
 	for (uint32_t v = 1; v < S; v++) {
 		const uint32_t *dv = &delta[(size_t)v * NC];
-		for (uint32_t e = ent_off[v]; e < ent_off[v + 1]; e++) {
-			const uint32_t c = ent_code[e], u = dv[c], t = base[v] + c;
-			uint32_t w = c << 16 | base[u];
-			if (out_link[u] != 0) {
-				w |= DfaImage::kArr;
-				out->out_first[t] = records_of(u);
+		for (int q = 0; q < 4; q++) {
+			for (uint64_t m = row[v].w[q]; m; m &= m - 1) {
+				const uint32_t c = 64 * q + (uint32_t)__builtin_ctzll(m), u = dv[c], t = base[v] + c;
+				uint32_t w = c << 16 | base[u];
+				if (out_link[u] != 0) {
+					w |= DfaImage::kArr;
+					const uint32_t o = records_of(u), r = out->out_list[o];
+					if (r & 0x80000000u) { // one string ends here: its record in place of the list's index, its length in the word
+						out->out_first[t] = r | SearchImage::kInline;
+						const uint32_t len = (r >> 16) & 0x3FFFu;
+						if (len <= 63) w |= len << SearchImage::kLenShift;
+					} else out->out_first[t] = o;
+				}
+				out->hot[t] = w;
+				entries++;
 			}
-			out->hot[t] = w;
 		}
 	}
-	out->entries = (uint32_t)ent_code.size();
+	out->entries = entries;
 	out->hot_slots = top, out->stride = stride, out->max_len = max_len, out->states = S;
 	return true;
 }
@@ -899,10 +911,15 @@ void SearchRun(const SearchImage &img, const uint8_t *text, uint64_t n, std::vec
 		if (((x >> DfaImage::kLabelShift) & DfaImage::kLabelMask) == c) {
 			S = x;
 			if (x & DfaImage::kArr) {
-				for (uint32_t o = img.out_first[t];; o++) {
-					const uint32_t r = img.out_list[o];
-					found->emplace_back(r & 0xFFFFu, i + 1 - ((r >> 16) & 0x7FFFu));
-					if (r & 0x80000000u) break;
+				const uint32_t f = img.out_first[t];
+				if (f & SearchImage::kInline) {
+					found->emplace_back(f & 0xFFFFu, i + 1 - ((f >> 16) & 0x3FFFu));
+				} else {
+					for (uint32_t o = f;; o++) {
+						const uint32_t r = img.out_list[o];
+						found->emplace_back(r & 0xFFFFu, i + 1 - ((r >> 16) & 0x3FFFu));
+						if (r & 0x80000000u) break;
+					}
 				}
 			}
 		} else S = c * img.stride;

@@ -134,10 +134,15 @@ struct DfaOptions {
 // one-byte string is never toggled as a token end (the root row is all token ends).
 struct SearchImage {
 	std::vector<uint32_t> hot;       // [hot_slots] DfaImage's word layout; the start state is word 0 (base 0, an empty row)
-	std::vector<uint32_t> out_first; // [hot_slots] by entry: index into out_list, kNone where nothing ends
-	std::vector<uint32_t> out_list;  // string k | bytes << 16 | 0x80000000 on the last of an entry's records
+	std::vector<uint32_t> out_first; // [hot_slots] by entry: kNone where nothing ends; kInline | the record itself where one string ends; else the index of the first record in out_list
+	std::vector<uint32_t> out_list;  // string k | bytes << 16 (14 bits) | 0x80000000 on the last of an entry's records
 	uint32_t hot_slots = 0, stride = 0, max_len = 0, states = 0, entries = 0;
 	static constexpr uint32_t kNone = 0xFFFFFFFFu;
+	static constexpr uint32_t kInline = 0x40000000u;
+	// bits 24 .. 29 of an entry's word (unused by the step): the bytes of the one string that ends there, 0 = look it up
+	// (several strings, or more than 63 bytes) -- the scan passes them on with its record, so that whoever reads the record
+	// can tell where the string starts before any table is read
+	static constexpr uint32_t kLenShift = 24;
 };
 // strings: codes[off[k] .. off[k + 1]) for k < n, no code 0 and none >= ncodes inside.  false: the automaton does not fit
 // max_slots (the caller searches another way).

@@ -123,7 +123,7 @@ struct StreamWork {
 	const uint32_t *tg_count = nullptr; // [kToggleLists] items appended per list (may exceed tg_cap: the surplus was not stored)
 	uint32_t tg_cap = 0;                // per list
 	const uint32_t *tg_index = nullptr; // optional: list entry -> item (the lists then hold indices into tg_items, tg_n)
-	const uint32_t *tg_n = nullptr;     // optional, by item: the item's n (above kToggleOffsets: the whole stream), instead of ToggleItem::n
+	const uint32_t *tg_n = nullptr;     // optional, by item: the item's n - 1 (n above kToggleOffsets: the whole stream), instead of ToggleItem::n
 	const uint32_t *tg_slot = nullptr;  // [moves] the slot whose token-end bit the move flips
 	unsigned long long *tg_delta = nullptr; // [moves] tokens with the move - tokens without, mod 2^64
 	uint32_t tg_moves = 0;              // optional: moves of the batch (the local walks then add up per workgroup first)
@@ -268,7 +268,7 @@ struct SearchDev {
 // the kToggleLists lists list_index (StreamWork::tg_index; tg_n = count: an item's n)
 struct SearchItems {
 	unsigned long long *keys;  // [slots] 0 = free, else (string << 32 | stream) + 1
-	uint32_t *count;           // [slots] occurrences on a token start seen for the key (zeroed by the caller, with keys)
+	uint32_t *count;           // [slots] occurrences on a token start seen for the key after the first (zeroed by the caller, with keys)
 	ToggleItem *items;         // [slots] stream, move (= string), off[] filled here; n is `count`
 	uint32_t mask;             // slots - 1, slots a power of two
 	uint32_t *flags;           // [0] != 0: the table was full (the caller comes again with a larger one)

@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(1024) dfa_search_kernel(SearchDev A, DfaWork W
 					if (m != 0) {
 						if (arr) {
 							const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-							reinterpret_cast<uint2 *>(la.base)[la.cur / 4 + rank] = uint2{t | (i + 1) << 16, P[j] + W.range_bytes + i};
+							reinterpret_cast<uint2 *>(la.base)[la.cur / 4 + rank] = uint2{t | ((x >> 24) & 63u) << 16 | (i + 1) << 24, P[j] + W.range_bytes + i};
 						}
 						la.cur += 4 * (uint32_t)__builtin_popcountll(m);
 						if (la.cur * 2 > kHighBytes) la.roll(Qa, lane);
@@ -416,12 +416,16 @@ __device__ __forceinline__ uint32_t search_emit(const SearchItems &H, uint32_t s
 	uint32_t h = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 32) & H.mask;
 	uint32_t claimed = kNoSlot;
 	for (uint32_t tries = 0;; tries++) {
-		// (most keys are new: the exchange straight away, not a look first)
-		unsigned long long seen = atomicCAS(&H.keys[h], 0ull, key);
+		// (a look first: a slot somebody else's key holds costs no atomic -- device-wide atomics are what this kernel
+		// waits for.  A key is written once, over 0: a stale 0 only sends the exchange, which then returns what is there)
+		unsigned long long seen = *(volatile unsigned long long *)&H.keys[h];
 		if (seen == 0) {
-			H.items[h].stream = l, H.items[h].move = string;
-			claimed = h;
-			seen = key;
+			seen = atomicCAS(&H.keys[h], 0ull, key);
+			if (seen == 0) {
+				H.items[h].stream = l, H.items[h].move = string;
+				claimed = h;
+				seen = key;
+			}
 		}
 		if (seen == key) break;
 		h = (h + 1) & H.mask;
@@ -430,7 +434,11 @@ __device__ __forceinline__ uint32_t search_emit(const SearchItems &H, uint32_t s
 			return kNoSlot;
 		}
 	}
-	const uint32_t k = rel < 0xFFFFu ? atomicAdd(&H.count[h], 1u) : atomicAdd(&H.count[h], 1000u);
+	// (device-wide atomics are what this kernel waits for: whoever claimed the slot takes offset 0 without one --
+	// `count` is the occurrences after the first)
+	uint32_t k = 0;
+	if (claimed == kNoSlot) k = 1u + atomicAdd(&H.count[h], 1u);
+	if (rel >= 0xFFFFu) k = kToggleOffsets + atomicAdd(&H.count[h], 1000u); // (a stream of 64 KB and more: walked whole)
 	if (k < kToggleOffsets) H.items[h].off[k] = (uint16_t)rel;
 	return claimed;
 }
@@ -443,9 +451,15 @@ __device__ __forceinline__ void search_list(const SearchItems &H, uint32_t q, ui
 __device__ __forceinline__ uint32_t search_emit_all(const SearchDev &A, const SearchItems &H, uint32_t entry, uint32_t last_byte, uint32_t below,
                                                     uint32_t list) {
 	uint32_t claimed = kNoSlot;
-	for (uint32_t o = A.out_first[entry]; o != 0xFFFFFFFFu; o++) {
+	const uint32_t f = A.out_first[entry];
+	if (f & 0x40000000u) { // (SearchImage::kInline: one string)
+		if (f == 0xFFFFFFFFu) return kNoSlot;
+		const uint32_t first = last_byte + 1 - ((f >> 16) & 0x3FFFu);
+		return first < below ? search_emit(H, f & 0xFFFFu, first) : kNoSlot;
+	}
+	for (uint32_t o = f;; o++) {
 		const uint32_t r = A.out_list[o];
-		const uint32_t first = last_byte + 1 - ((r >> 16) & 0x7FFFu);
+		const uint32_t first = last_byte + 1 - ((r >> 16) & 0x3FFFu);
 		if (first < below) {
 			const uint32_t c = search_emit(H, r & 0xFFFFu, first);
 			if (c != kNoSlot) {
@@ -481,9 +495,19 @@ __global__ void __launch_bounds__(256) search_items_kernel(SearchDev A, StreamDe
 					const uint2 r = rec[(size_t)bt * (kDfaBatchEntries / 4) + i0 + lane];
 					// (r.x >> 16: found that many bytes behind a range boundary, by the lane of the range before it: the
 					// strings that begin before the boundary are its own)
-					const uint32_t behind = r.x >> 16;
-					claimed = search_emit_all(A, H, r.x & 0xFFFFu, r.y, behind ? r.y + 1 - behind : 0xFFFFFFFFu, my_list);
+					const uint32_t behind = r.x >> 24, len = (r.x >> 16) & 63u;
+					// (len: the bytes of the one string that ends there, where the entry's word could say so: three of four
+					// occurrences lie inside a token of the vocabulary as it is, and are dropped here before any table is read)
+					const uint32_t q = r.y + 1 - len;
+					if (len == 0 || ((H.starts[q >> 6] >> (q & 63)) & 1ull))
+						claimed = search_emit_all(A, H, r.x & 0xFFFFu, r.y, behind ? r.y + 1 - behind : 0xFFFFFFFFu, my_list);
 				}
+#ifdef DFA_EXP_STATS // (csrc/Makefile exp_dfa: records read, for the trace line of score_toggles_by_search)
+				{
+					const unsigned long long mr = __builtin_amdgcn_ballot_w64(i0 + lane < n);
+					if (lane == 0) atomicAdd(&H.flags[2], (uint32_t)__builtin_popcountll(mr));
+				}
+#endif
 				const unsigned long long m = __builtin_amdgcn_ballot_w64(claimed != kNoSlot);
 				if (m != 0) {
 					uint32_t at = 0;

@@ -199,7 +199,8 @@ struct tokscore_ctx {
 	uint64_t knob_search_moves = 256; // TOKSCORE_SEARCH_MOVES: moves per pass
 	unsigned char *d_sr_table = nullptr; // keys u64[slots] | count u32[slots] | items ToggleItem[slots]
 	size_t sr_table_bytes = 0;
-	uint64_t sr_slots_hint = 1u << 20;
+	uint64_t sr_slots_hint = 1u << 16;
+	bool sr_slots_fixed = false;   // TOKSCORE_SEARCH_SLOTS given: the first table exactly that (tests)
 	uint32_t *d_block_stream = nullptr; // per stream plan
 	uint64_t search_batches = 0;    // batches judged this way (diagnostics)
 	// occurrence index (one bit per string and chunk), built by the first incremental re-score of a plan
@@ -1552,7 +1553,8 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->knob_nobatch = env_u64("TOKSCORE_NOBATCH", 0) != 0;
 	c->knob_search = env_u64("TOKSCORE_SEARCH", 1) != 0;
 	c->knob_search_moves = std::min<uint64_t>(0xFFFF, std::max<uint64_t>(1, env_u64("TOKSCORE_SEARCH_MOVES", 256)));
-	c->sr_slots_hint = std::max<uint64_t>(1024, env_u64("TOKSCORE_SEARCH_SLOTS", 1u << 20));
+	c->sr_slots_fixed = getenv("TOKSCORE_SEARCH_SLOTS") != nullptr;
+	c->sr_slots_hint = std::max<uint64_t>(1024, env_u64("TOKSCORE_SEARCH_SLOTS", 1u << 16));
 	c->knob_no_mark_ranges = env_u64("TOKSCORE_NOMARKRANGES", 0) != 0;
 	c->knob_incr_div = getenv("TOKSCORE_INCR_DIV") ? std::max<uint64_t>(1, env_u64("TOKSCORE_INCR_DIV", 3)) : 0;
 	c->knob_toggle_items = std::max<uint64_t>(1, env_u64("TOKSCORE_TOGGLE_ITEMS", 32ull << 20));
@@ -2079,15 +2081,17 @@ int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s
 	}
 	const DfaScanPlan &P = c->dplan;
 	const uint32_t first_batches = P.blocks * P.waves_per_block;
-	if (c->dstream_cap < first_batches + 16 || img.max_len > P.range_bytes) return 1; // (a string crosses one range boundary at most)
+	if (c->dstream_cap < first_batches + 16 || img.max_len > P.range_bytes || img.max_len > 256) return 1; // (a string crosses one range boundary at most; a record says in 8 bits how far behind it)
 	// blob (32-bit words): delta u64[n] | flags[2] | cursor[2] | list counts[kToggleLists] | slots[n] | hot | out_first | out_list
 	const size_t hot_words = ((size_t)img.hot_slots + 19) & ~(size_t)3; // (16 bytes of padding the kernel's 16-byte copies may read)
-	const size_t flags_at = 2 * (size_t)n, cursor_at = flags_at + 2, lists_at = cursor_at + 2, slots_at = lists_at + kToggleLists;
+	const size_t flags_at = 2 * (size_t)n, cursor_at = flags_at + 4, lists_at = cursor_at + 2, slots_at = lists_at + kToggleLists;
 	const size_t hot_at = (slots_at + n + 3) & ~(size_t)3, first_at = hot_at + hot_words, list_at = first_at + hot_words;
 	const size_t words = list_at + img.out_list.size() + 4;
 	for (;;) {
 		uint64_t slots = 1024;
-		while (slots < c->sr_slots_hint) slots <<= 1;
+		// (a move's string sits on a token start in a few thousand of a 100 MB shard's streams: four slots per item)
+		const uint64_t want = c->sr_slots_fixed ? c->sr_slots_hint : std::max<uint64_t>(c->sr_slots_hint, (uint64_t)n * (c->prep_total / 8192 + 1024));
+		while (slots < want) slots <<= 1;
 		if (slots > (1ull << 28)) return 1;
 		const uint32_t list_cap = (uint32_t)(slots / 32); // (items <= slots / 2 in a table that is not full, spread evenly over the lists: four times their share)
 		const size_t table_bytes = slots * (sizeof(unsigned long long) + sizeof(uint32_t) + sizeof(ToggleItem)) + (size_t)kToggleLists * list_cap * sizeof(uint32_t);
@@ -2138,8 +2142,8 @@ int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s
 		const double t_l = now();
 		HIP_TRY(c, hipStreamSynchronize(s));
 		if (trace)
-			fprintf(stderr, "score_toggles by search: automaton %.0f us (%u states, %u entries, %u slots), launches %.0f, wait %.0f\n", t_img - t0,
-			        img.states, img.entries, img.hot_slots, t_l - t_img, now() - t_l);
+			fprintf(stderr, "score_toggles by search: automaton %.0f us (%u states, %u entries, %u slots), launches %.0f, wait %.0f; table %llu slots, records %u\n",
+			        t_img - t0, img.states, img.entries, img.hot_slots, t_l - t_img, now() - t_l, (unsigned long long)slots, h[flags_at + 2]);
 		uint64_t made = 0;
 		uint32_t most = 0;
 		for (uint32_t q = 0; q < kToggleLists; q++) made += h[lists_at + q], most = std::max(most, h[lists_at + q]);
@@ -2147,6 +2151,7 @@ int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s
 		const uint32_t overflow = h[cursor_at + 1];
 		if (overflow) return fail(c, TOKSCORE_E_CAPACITY, "search records overflow (internal capacity bound violated)");
 		if (made * 4 > slots) c->sr_slots_hint = std::max<uint64_t>(c->sr_slots_hint, made * 8); // (the next batch)
+		if (trace) fprintf(stderr, "score_toggles by search: %llu items, longest list %u of %u%s\n", (unsigned long long)made, most, list_cap, full ? ", again with a larger table" : "");
 		if (full) {
 			c->sr_slots_hint = std::max<uint64_t>(2 * slots, made * 8);
 			continue;

@@ -213,7 +213,8 @@ def gen(C, exp=()):
                  "v_mbcnt_lo_u32_b32 v20, exec_lo, 0",
                  "v_mbcnt_hi_u32_b32 v20, exec_hi, v20",
                  "v_lshl_add_u32 v20, v20, 3, %[cura]",
-                 "v_mov_b32 %s, %s" % (v(j, "M"), v(j, T)),
+                 "v_bfe_u32 %s, %s, 24, 6" % (v(j, "M"), nxt(j, k)),          # (dfa.h: SearchImage::kLenShift)
+                 "v_lshl_or_b32 %s, %s, 16, %s" % (v(j, "M"), v(j, "M"), v(j, T)),
                  "v_add_u32 %s, s68, %%[P%d]" % (v(j, "R"), j),
                  "global_store_dwordx2 v20, v[%s:%s], %%[basea]" % (v(j, "M")[1:], v(j, "R")[1:]),
                  "s_bcnt1_i32_b64 s68, exec",
