@@ -127,8 +127,10 @@ def test_gpu_candidates_equal_host_builder(kind, nbytes, max_cp):
     assert got[4] == int(want[1][roots].sum())
 
 
-def test_gpu_candidates_shard_by_shard_equal_host_builder_on_all():
-    # three shards extracted one after the other and merged on the host = one trie over all files
+@pytest.mark.parametrize("group_bytes", [1 << 30, 1, 450_000])
+def test_gpu_candidates_shard_by_shard_equal_host_builder_on_all(group_bytes):
+    # three shards = one trie over all files: extracted together by one sort on the GPU (the default: they fit one
+    # group) / one after the other and merged on the host / two groups (the first two shards together, then the third)
     shards = [synth.wiki_like(300_000, seed=61, n_words=3000, median_doc=500),
               synth.cjk_heavy(120_000, seed=62, doc_lo=16, doc_hi=2000),
               synth.wiki_like(200_000, seed=63, n_words=3000, median_doc=900)]
@@ -137,7 +139,7 @@ def test_gpu_candidates_shard_by_shard_equal_host_builder_on_all():
         raw = b.tobytes()
         docs += [raw[int(o[i]):int(o[i + 1])] for i in range(len(o) - 1)]
     want = A.GetTokens(*synth.pack_docs(docs), 6).arrays()
-    got = A.GetTokensGpu(shards, max_len=6).arrays()
+    got = A.GetTokensGpu(shards, max_len=6, group_bytes=group_bytes).arrays()
     for name, a, b in zip(("chr", "uses", "lpar", "rpar"), got, want):
         assert np.array_equal(a, b), name
     one = A.GetTokensGpu(*shards[0], max_len=6).arrays()

@@ -191,17 +191,43 @@ def GetTokens(corpus: np.ndarray, doc_off: np.ndarray, max_len: int = 255) -> To
     return Tokens(h.value)
 
 
-def GetTokensGpu(corpus, doc_off=None, max_len: int = 255, device: int = 0) -> Tokens:
+def GetTokensGpu(corpus, doc_off=None, max_len: int = 255, device: int = 0, group_bytes: int = 1 << 30) -> Tokens:
     """The same candidate set as GetTokens, computed on the GPU (tokscore_extract_candidates: one
     sort of all windows instead of a trie; max_len <= 32, valid UTF-8 without NUL bytes).
-    `corpus` may also be a list of (bytes, offsets) shards, each below 4 GiB: they are extracted
-    one after the other and merged on the host, like the files of one metadata.json."""
+    `corpus` may also be a list of (bytes, offsets) shards, like the files of one metadata.json.
+    Documents are independent and the extraction is one sort of all their windows, so shards are not
+    merged: as many as fit `group_bytes` (below 4 GiB: 32-bit positions; about 80 bytes of HBM per
+    corpus byte while it runs) are put behind one another and extracted TOGETHER -- the sort does the
+    merging, on the GPU.  Only the sets of different groups go through the host's merge
+    (tokanneal_cands_merge, 28 M tokens/s)."""
     from . import Scorer
     shards = [(corpus, doc_off)] if doc_off is not None else list(corpus)
+    group_bytes = max(1, min(int(group_bytes), (1 << 32) - (1 << 24)))
+    groups, cur, cur_bytes = [], [], 0
+    for b, o in shards:
+        b = np.ascontiguousarray(b, dtype=np.uint8)
+        o = np.ascontiguousarray(o, dtype=np.uint64)
+        n = int(o[-1] - o[0])
+        if cur and cur_bytes + n > group_bytes:
+            groups.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append((b, o))
+        cur_bytes += n
+    if cur:
+        groups.append(cur)
     s = Scorer(device)
     total = None
     try:
-        for b, o in shards:
+        for g in groups:
+            if len(g) == 1:
+                b, o = g[0]
+            else:  # one corpus: the shards' bytes behind one another, the offsets shifted
+                b = np.concatenate([x[int(y[0]):int(y[-1])] for x, y in g])
+                parts, base = [np.zeros(1, dtype=np.uint64)], 0
+                for _, y in g:
+                    parts.append((y[1:] - y[0]) + np.uint64(base))
+                    base += int(y[-1] - y[0])
+                o = np.concatenate(parts)
             s.set_corpus(b, o)
             chr_, uses, lpar, rpar, _ = s.extract_candidates(max_len)
             part = Tokens.from_arrays(chr_, uses, lpar, rpar)

@@ -126,6 +126,7 @@ struct StreamWork {
 	const uint32_t *tg_n = nullptr;     // optional, by item: the item's n - 1 (n above kToggleOffsets: the whole stream), instead of ToggleItem::n
 	const uint32_t *tg_slot = nullptr;  // [moves] the slot whose token-end bit the move flips
 	unsigned long long *tg_delta = nullptr; // [moves] tokens with the move - tokens without, mod 2^64
+	uint32_t tg_whole = kToggleOffsets; // with tg_n: items of more occurrences than this are walked whole (launch_walk_toggles), the others locally
 	uint32_t tg_moves = 0;              // optional: moves of the batch (the local walks then add up per workgroup first)
 };
 constexpr uint32_t kToggleLists = 64; // the items of a batch are kept in this many lists, one per lane of the walk

@@ -579,7 +579,7 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 						size_t at = (size_t)q * W.tg_cap + idx;
 						if (W.tg_index) at = W.tg_index[at];
 						const ToggleItem *it = &W.tg_items[at];
-						have = W.tg_n ? W.tg_n[at] + 1u > kToggleOffsets : it->n == kToggleWhole; // (the others: local_toggles_kernel)
+						have = W.tg_n ? W.tg_n[at] + 1u > W.tg_whole : it->n == kToggleWhole; // (the others: local_toggles_kernel)
 						strm = it->stream;
 						move = it->move;
 						if (have) flip_slot = W.tg_slot[move];
@@ -859,7 +859,7 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 			ToggleItem it = W.tg_items[at];
 			if (W.tg_n) { // ... and the count of the occurrences after the first is kept beside them)
 				const uint32_t n = W.tg_n[at] + 1u;
-				it.n = n > kToggleOffsets ? kToggleWhole : (uint16_t)n;
+				it.n = n > W.tg_whole ? kToggleWhole : (uint16_t)n;
 			}
 			if (it.n != kToggleWhole && it.n != 0) {
 				move = it.move;

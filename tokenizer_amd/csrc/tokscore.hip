@@ -197,6 +197,7 @@ struct tokscore_ctx {
 	// index and a search per (move, chunk): the (move, stream) table, the stream of every 256-byte block of the prepared corpus
 	bool knob_search = true;        // TOKSCORE_SEARCH=0: the index and per-chunk searches
 	uint64_t knob_search_moves = 256; // TOKSCORE_SEARCH_MOVES: moves per pass
+	uint32_t knob_search_whole = kToggleOffsets; // TOKSCORE_SEARCH_WHOLE: a stream with more occurrences of a move's string than this is walked whole
 	unsigned char *d_sr_table = nullptr; // keys u64[slots] | count u32[slots] | items ToggleItem[slots]
 	size_t sr_table_bytes = 0;
 	uint64_t sr_slots_hint = 1u << 16;
@@ -1552,6 +1553,7 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->knob_noincr = env_u64("TOKSCORE_NOINCR", 0) != 0;
 	c->knob_nobatch = env_u64("TOKSCORE_NOBATCH", 0) != 0;
 	c->knob_search = env_u64("TOKSCORE_SEARCH", 1) != 0;
+	c->knob_search_whole = (uint32_t)std::min<uint64_t>(kToggleOffsets, std::max<uint64_t>(1, env_u64("TOKSCORE_SEARCH_WHOLE", kToggleOffsets)));
 	c->knob_search_moves = std::min<uint64_t>(0xFFFF, std::max<uint64_t>(1, env_u64("TOKSCORE_SEARCH_MOVES", 256)));
 	c->sr_slots_fixed = getenv("TOKSCORE_SEARCH_SLOTS") != nullptr;
 	c->sr_slots_hint = std::max<uint64_t>(1024, env_u64("TOKSCORE_SEARCH_SLOTS", 1u << 16));
@@ -2132,6 +2134,7 @@ int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s
 		W.tg_index = list_index;
 		W.tg_n = count;
 		W.tg_moves = n;
+		W.tg_whole = c->knob_search_whole;
 		W.tg_slot = d + slots_at;
 		W.tg_base = c->d_stream_tokens;
 		W.tg_delta = reinterpret_cast<unsigned long long *>(d);
