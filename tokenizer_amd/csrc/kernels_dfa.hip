@@ -286,11 +286,14 @@ __global__ void __launch_bounds__(1024) dfa_scan_asm_kernel(DfaDev A, DfaWork W,
 			uint32_t voff = lane * 8 + p * (C * 512);
 			uint32_t curm = uni32(lm.cur * 2), cura = uni32(la.cur * 2);
 			const unsigned long long basem = uni64((unsigned long long)(uintptr_t)lm.base), basea = uni64((unsigned long long)(uintptr_t)la.base);
+			// the miss batch as a buffer of 16-bit records (stride 2): a store's index is the lane's rank among the step's
+			// events, its scalar offset the fill in bytes; what lies beyond the batch is dropped by the range check
+			const u32x4 srd = {uni32((uint32_t)basem), uni32((uint32_t)(basem >> 32) & 0xFFFFu) | (2u << 16), kDfaBatchEntries, 0x00020000u};
 			uint32_t pp = uni32(p);
 #define DFA_OPERANDS                                                                                                         \
 	[p] "+s"(pp), [curm] "+s"(curm), [cura] "+s"(cura), [voff] "+v"(voff), [S0] "+v"(S[0]), [G0] "+v"(G[0]), [S1] "+v"(S[1]),         \
 	    [G1] "+v"(G[1]), [S2] "+v"(S[2]), [G2] "+v"(G[2]), [S3] "+v"(S[3]), [G3] "+v"(G[3])                                           \
-	    : [src] "s"(src), [pieces] "s"(pieces), [hot] "s"(hot_slots), [high] "s"(kHighBytes), [basem] "s"(basem),                    \
+	    : [src] "s"(src), [pieces] "s"(pieces), [hot] "s"(hot_slots), [high] "s"(kHighBytes), [srd] "s"(srd),                        \
 	      [basea] "s"(basea), [slot] "s"(slot_p), [gof] "s"(gof_p), [cmiss] "s"(cmiss_p), [carr] "s"(carr_p), [chit] "s"(chit_p),    \
 	      [stride] "v"(stride), [coldb] "v"(cold_base), [coldbs] "s"(cold_base_s)
 			if constexpr (C == 1) {

@@ -269,13 +269,14 @@ def gen(C, exp=()):
                 main.append("v_mbcnt_lo_u32_b32 %s, %s, 0" % (v(j, "R"), mlo(j)))
             for j in range(C):
                 main.append("v_mbcnt_hi_u32_b32 %s, %s, %s" % (v(j, "R"), mhi(j), v(j, "R")))
-            for j in range(C):  # (the stream's fill moves on chain by chain)
-                main.append("v_lshl_add_u32 %s, %s, 1, %%[curm]" % (v(j, "R"), v(j, "R")))
-                main.append("s_bcnt1_i32_b64 %s, %s" % (cnt(j), m(j)))
-                main.append("s_lshl1_add_u32 %%[curm], %s, %%[curm]" % cnt(j))
+            # (the batch as a buffer of 16-bit records: the store's index is the rank, its scalar offset the stream's fill in
+            # bytes -- the address arithmetic a global store needs, "rank * 2 + fill", is the hardware's.  The fill moves on
+            # chain by chain, so every chain's store goes with the fill before it: stores and scalar adds alternate.)
             for j in range(C):
                 main.append("s_or_b64 exec, %s, s[78:79]" % m(j))
-                main.append("global_store_short %s, %s, %%[basem]" % (v(j, "R"), cur(j, k)))
+                main.append("buffer_store_short %s, %s, %%[srd], %%[curm] idxen" % (cur(j, k), v(j, "R")))
+                main.append("s_bcnt1_i32_b64 %s, %s" % (cnt(j), m(j)))
+                main.append("s_lshl1_add_u32 %%[curm], %s, %%[curm]" % cnt(j))
             main.append("s_mov_b64 exec, -1")
 
     # ---- the loop
