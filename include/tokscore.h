@@ -230,6 +230,10 @@ typedef struct {
 	uint64_t dfa_second_hits;   /* lookups the L2 array answered with a hit, when the scan's counters were last read */
 	uint32_t dfa_relayouts;     /* times those counters were read to choose again what LDS holds (once per vocabulary state; TOKSCORE_DFA_RELAYOUTS) */
 	uint32_t search_passes;     /* passes of a search automaton over the corpus that tokscore_score_toggles has made (up to 256 moves each) */
+	uint32_t dfa_form;          /* 0: no image; 1: flattened (one lookup per byte, virtual entries); 2: failure form (the trie's own
+	                             * edges + one failure entry per state, f followed state by state: vocabularies whose prefixes are
+	                             * mostly not tokens, e.g. what TokenGenerator::GetSolution writes) */
+	uint32_t reserved0;
 } tokscore_info;
 int tokscore_get_info(tokscore_ctx *ctx, tokscore_info *info);
 

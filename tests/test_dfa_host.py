@@ -15,8 +15,15 @@ def _host_scorer(tokens):
     return s
 
 
+@pytest.fixture(params=["flattened", "failure"])
+def form(request, monkeypatch):
+    """Both forms of the automaton (dfa.h): every byte taken at once (virtual entries), or f followed state by state."""
+    monkeypatch.setenv("TOKSCORE_HOSTDFA_FAIL", "1" if request.param == "failure" else "0")
+    return request.param
+
+
 @pytest.mark.parametrize("case", O.golden_cases())
-def test_automaton_matches_reference_golden(case):
+def test_automaton_matches_reference_golden(case, form):
     g = O.load_golden(case)
     corpus, off = synth.pack_docs(g["docs"])
     if any(b"\x00" in d for d in g["docs"]):
@@ -34,7 +41,7 @@ def test_automaton_matches_reference_golden(case):
 
 
 @pytest.mark.parametrize("kind", ["wiki", "cjk"])
-def test_automaton_matches_oracle_on_synthetic(kind):
+def test_automaton_matches_oracle_on_synthetic(kind, form):
     if kind == "wiki":
         corpus, off = synth.wiki_like(1_500_000, seed=11)
         tokens = synth.build_vocab(corpus[:600_000], 8000)

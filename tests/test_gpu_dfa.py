@@ -125,11 +125,75 @@ def test_automaton_scan_after_toggles():
     s.close()
 
 
+FAIL_FORM = {"TOKSCORE_DFA_FORM": "2"}
+
+
+@pytest.mark.parametrize("chains", ["1", "2", "4"])
+@pytest.mark.parametrize("lds", ["0", "3000"])
+def test_failure_form_matches_oracle(chains, lds):
+    # the same vocabulary in the failure form (f followed state by state, lanes with byte windows of their own): with
+    # all of LDS nearly every lookup is answered there, with 3,000 slots most rows are only in the global array
+    corpus, off = synth.wiki_like(3_000_000, seed=21)
+    tokens = synth.build_vocab(corpus[:800_000], 12000)
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    with _Env(TOKSCORE_DFA_CHAINS=chains, TOKSCORE_DFA_LDS=lds, **FAIL_FORM):
+        s = ta.Scorer(0)
+    s.set_vocab(*synth.pack_vocab(tokens))
+    s.set_corpus(corpus, off)
+    _check(s, voc, corpus, off, "first evaluation (every range entry repaired)")
+    info = s.info()
+    assert info.dfa_active == 1 and info.scan_path == 2 and info.dfa_chains == int(chains) and info.dfa_form == 2
+    assert info.dfa_virtual_slots == 0
+    _check(s, voc, corpus, off, "second evaluation (what LDS holds chosen again from the first one's counters)")
+    _check(s, voc, corpus, off, "third evaluation (the global array's hits no longer counted)")
+    _check(s, voc, corpus, off, "fourth evaluation")
+    s.close()
+
+
+def test_failure_form_ragged_documents_and_toggles():
+    rng = np.random.default_rng(6)
+    base, boff = synth.wiki_like(400_000, seed=22)
+    tokens = synth.build_vocab(base[:200_000], 3000)
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    raw = base.tobytes()
+    docs = [b"", b"a", b"", raw[:7], raw[1000:1003], b"", raw[5000:5000 + 70_001], b"Q", b""]
+    docs += [raw[int(p):int(p) + int(n)] for p, n in zip(rng.integers(0, 300_000, 300), rng.integers(0, 40, 300))]
+    for sub in (docs, docs[:3], [b""], [b"xyz"], [raw[:100_000]]):
+        corpus, off = synth.pack_docs(sub)
+        with _Env(**FAIL_FORM):
+            s = ta.Scorer(0)
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        _check(s, voc, corpus, off, len(sub))
+        if len(corpus):
+            assert s.info().dfa_active == 1 and s.info().dfa_form == 2
+        _check(s, voc, corpus, off, len(sub))
+        s.close()
+    # toggles: the plan's scan serves the evaluations until the image has been rebuilt, in the same form
+    corpus, off = synth.wiki_like(1_500_000, seed=23)
+    with _Env(**FAIL_FORM):
+        s = ta.Scorer(0)
+    s.set_vocab(*synth.pack_vocab(tokens))
+    s.set_corpus(corpus, off)
+    _check(s, voc, corpus, off)
+    multi = [i for i, t in enumerate(tokens) if len(t) > 1]
+    gone = set(int(i) for i in rng.choice(multi, size=6, replace=False))
+    for i in gone:
+        s.toggle(i, False)
+    voc2 = O.OracleVocab(*synth.pack_vocab([b"" if i in gone else t for i, t in enumerate(tokens)]))
+    _check(s, voc2, corpus, off, "after toggles")
+    assert s.info().dfa_active == 0
+    _check(s, voc2, corpus, off)
+    assert s.info().dfa_active == 1 and s.info().dfa_form == 2
+    _check(s, voc2, corpus, off)
+    s.close()
+
+
 def test_reference_annealer_vocabulary():
     # tests/golden/wiki_annealed: 30,275 tokens the reference's own TokenGenerator wrote, 124,789 trie
-    # nodes, most prefixes not tokens -- 2.8 M virtual slots, a third of the steps arrive on one and almost
-    # half of the lookups need the global array: the library leaves it to the plan's scan (tokscore.hip:
-    # ensure_dfa), and the automaton, when forced, still counts exactly
+    # nodes, most prefixes not tokens -- flattened that is 2.8 M virtual slots, a third of the steps arrive on one
+    # and almost half of the lookups need the global array, so the library takes the failure form for it
+    # (tokscore.hip: ensure_dfa); the flattened form, when forced, still counts exactly
     g = O.load_golden("wiki_annealed")
     corpus, off = synth.pack_docs(g["docs"])
     for force in (False, True):
@@ -142,9 +206,12 @@ def test_reference_annealer_vocabulary():
             assert tt == g["expected"]["total_tokens"] and tb == g["expected"]["total_bytes"]
             assert np.array_equal(counts, g["expected"]["counts_vec"])
         info = s.info()
-        assert info.dfa_active == (1 if force else 0)
+        assert info.dfa_active == 1 and info.scan_path == 2
+        assert info.dfa_form == (1 if force else 2)
         if force:
-            assert info.scan_path == 2 and info.dfa_virtual_slots > 1_000_000 and info.dfa_slots > info.dfa_lds_slots
+            assert info.dfa_virtual_slots > 1_000_000 and info.dfa_slots > info.dfa_lds_slots
+        else:
+            assert info.dfa_virtual_slots == 0
         s.close()
     # ... and on a corpus it was not made from, against the oracle
     corpus, off = synth.wiki_like(4_000_000, seed=24)
@@ -160,8 +227,8 @@ def test_reference_annealer_vocabulary():
 
 
 def test_cjk_vocabulary():
-    # multibyte text: a tenth of the steps arrive on a virtual entry and more than a tenth of the lookups need the
-    # global array -- left to the plan's scan unless forced; exact either way
+    # multibyte text: flattened, a tenth of the steps arrive on a virtual entry and more than a tenth of the lookups
+    # need the global array -- the failure form (a twentieth) unless the flattened one is forced; exact either way
     corpus, off = synth.cjk_heavy(3_000_000, seed=5)
     tokens = synth.build_vocab(corpus[:1_000_000], 16000)
     voc = O.OracleVocab(*synth.pack_vocab(tokens))
@@ -172,7 +239,7 @@ def test_cjk_vocabulary():
         s.set_corpus(corpus, off)
         for _ in range(3):
             _check(s, voc, corpus, off)
-            assert s.info().dfa_active == (1 if force else 0)
+            assert s.info().dfa_active == 1 and s.info().dfa_form == (1 if force else 2)
         s.close()
 
 

@@ -80,6 +80,11 @@ DFA_CONFIGS = [
     dict(FORCE, TOKSCORE_DFA_CHAINS="1"),
     dict(FORCE, TOKSCORE_DFA_CHAINS="2", TOKSCORE_DFA_LDS="600"),
     dict(FORCE, TOKSCORE_SCAN="tile", TOKSCORE_DFA="1", TOKSCORE_DFA_LDS="2000"),
+    # the failure form of the automaton (dfa.h: DfaImage::fail_code; dfa_fscan_kernel), whatever the vocabulary's shape:
+    # four / one / two ranges per lane, and an LDS array so short that most rows are only in the global array
+    {"TOKSCORE_DFA_FORM": "2"},
+    {"TOKSCORE_DFA_FORM": "2", "TOKSCORE_DFA_CHAINS": "1"},
+    {"TOKSCORE_DFA_FORM": "2", "TOKSCORE_DFA_CHAINS": "2", "TOKSCORE_DFA_LDS": "600"},
 ]
 # goldens the automaton does not take (the plan's scan serves them): none any more (random_utf8's 190 distinct
 # edge bytes fit the label's byte since it became one)
@@ -112,6 +117,7 @@ def test_score_matches_reference_golden(case, cfg):
         # every other reference-generated golden, wiki_annealed (125 k trie nodes) included; with an LDS array of a
         # few hundred slots the depth-1 rows of the larger vocabularies do not fit, and the plan's scan serves them
         assert info.dfa_active == 1 and info.scan_path == 2, "the automaton scan was expected to serve the evaluation"
+        assert info.dfa_form == (2 if CONFIGS[cfg].get("TOKSCORE_DFA_FORM") == "2" else 1)
 
 
 @pytest.mark.parametrize("case", [c for c in O.golden_cases() if "ids" in O.load_golden(c)["expected"]])
@@ -210,10 +216,13 @@ def test_deep_128k_vocabulary_on_random_utf8():
     assert len(tokens) > 128_000
     voc = O.OracleVocab(*synth.pack_vocab(tokens))
     exp = voc.score(corpus, off, threads=8)
-    for cfg in ({"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "generic"}):
+    # ... and the automaton's failure form (3 M slots, half the lookups beyond LDS: never chosen for it, exact all the same)
+    for cfg in ({"TOKSCORE_SCAN": "tile"}, {"TOKSCORE_SCAN": "generic"}, {"TOKSCORE_DFA_FORM": "2"}):
         (counts, tt, tb), info = _score_with(cfg, tokens, corpus, off)
         assert (tt, tb) == exp[1:], cfg
         assert np.array_equal(counts, exp[0]), cfg
+        if "TOKSCORE_DFA_FORM" in cfg:
+            assert info.dfa_active == 1 and info.dfa_form == 2 and info.scan_path == 2
 
 
 def test_one_workgroup_sees_more_than_a_16_bit_row_holds():

@@ -34,7 +34,8 @@ class TokscoreInfo(C.Structure):
                 ("dfa_lds_slots", C.c_uint32), ("dfa_active", C.c_uint32), ("dfa_chains", C.c_uint32),
                 ("dfa_range_bytes", C.c_uint32), ("base_scan_path", C.c_uint32), ("dfa_lds_used", C.c_uint32),
                 ("dfa_hot_fraction", C.c_double), ("dfa_build_ms", C.c_double), ("dfa_plan_ms", C.c_double),
-                ("dfa_second_hits", C.c_uint64), ("dfa_relayouts", C.c_uint32), ("search_passes", C.c_uint32)]
+                ("dfa_second_hits", C.c_uint64), ("dfa_relayouts", C.c_uint32), ("search_passes", C.c_uint32),
+                ("dfa_form", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 # every symbol include/tokscore.h declares: (name, restype, argtypes)

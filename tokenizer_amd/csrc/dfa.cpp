@@ -67,7 +67,10 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	uint32_t k = 0;
 	for (uint32_t b = 1; b < 256; b++) k += is_label[b] ? 1 : 0;
 	const uint32_t ncodes = k + 2;
-	if (ncodes > DfaImage::kMaxCodes) return fail("too many distinct edge bytes (the label is a byte, all ones = empty)");
+	const bool fm = opt.fail_mode;
+	const uint32_t failc = ncodes;              // (failure form) the pseudo-code of a row's failure entry
+	const uint32_t ncr = ncodes + (fm ? 1 : 0); // codes a row can hold an entry for
+	if (ncr > DfaImage::kMaxCodes) return fail("too many distinct edge bytes (the label is a byte, all ones = empty)");
 	const uint32_t other = k + 1;
 	{
 		uint32_t next = 1;
@@ -172,7 +175,9 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 		std::vector<uint32_t> ids;
 		auto chain_ids = [&](uint32_t s) {
 			ids.clear();
-			for (uint32_t x = s; x != ROOT; x = f[x]) F_of(x, &ids);
+			if (fm) F_of(s, &ids); // (failure form: a miss emits F(s) alone, f is followed state by state)
+			else
+				for (uint32_t x = s; x != ROOT; x = f[x]) F_of(x, &ids);
 		};
 		for (uint32_t s = 1; s < S; s++) {
 			if (s < N && !reach[s]) continue;
@@ -198,7 +203,9 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 				seen[e[i].byte] = 1;
 				ent.push_back(Entry{e[i].child, DfaImage::kEvNone, code[e[i].byte], 0});
 			}
-			if (f[s] != ROOT) {
+			if (fm) {
+				if (f[s] != ROOT) ent.push_back(Entry{f[s], DfaImage::kEvNone, (uint8_t)failc, 0});
+			} else if (f[s] != ROOT) {
 				acc.clear();
 				F_of(s, &acc);
 				uint32_t arr_ev = 0;
@@ -247,11 +254,12 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	if (!reuse && opt.sample && opt.sample_bytes) {
 		// (a table entry-of(state, code) while it stays small: the search in the row cost 40 ns per sample byte)
 		std::vector<uint32_t> dense;
-		if ((uint64_t)S * ncodes <= (32u << 20)) {
-			dense.assign((size_t)S * ncodes, 0);
+		if ((uint64_t)S * ncr <= (32u << 20)) {
+			dense.assign((size_t)S * ncr, 0);
 			for (uint32_t s = 1; s < S; s++)
-				for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) dense[(size_t)s * ncodes + ent[j].code] = (uint32_t)j + 1;
+				for (uint64_t j = row_off[s]; j < row_off[s + 1]; j++) dense[(size_t)s * ncr + ent[j].code] = (uint32_t)j + 1;
 		}
+		auto find = [&](uint32_t st, uint32_t c) -> int64_t { return dense.empty() ? row_find(st, (uint8_t)c) : (int64_t)dense[(size_t)st * ncr + c] - 1; };
 		uint32_t st = d1[0];
 		for (uint64_t i = 0; i < opt.sample_bytes; i++) {
 			const uint8_t c = code[ascii_lower(opt.sample[i])];
@@ -262,7 +270,21 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 				continue;
 			}
 			w_row[st]++;
-			const int64_t j = dense.empty() ? row_find(st, c) : (int64_t)dense[(size_t)st * ncodes + c] - 1;
+			int64_t j = find(st, c);
+			if (fm) {
+				// (failure form: a miss is followed by the look at the row's failure entry, which counts as a lookup of
+				// the row and a use of that entry; the byte stays until some state takes it or the root is reached)
+				while (j < 0 && f[st] != ROOT) {
+					out->sample_miss++;
+					const int64_t jf = find(st, failc);
+					w_row[st]++;
+					w_ent[jf]++;
+					st = ent[jf].target;
+					w_row[st]++;
+					out->sample_steps++;
+					j = find(st, c);
+				}
+			}
 			if (j >= 0) {
 				w_ent[j]++;
 				out->sample_virtual += ent[j].virt;
@@ -313,7 +335,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	// long as entries fit: a row is there COMPLETE, or PARTIAL -- only the entries in use; a miss in a
 	// partial row proves nothing, so it is looked up again in the row's complete copy -- whichever is
 	// worth the slots: the rows with the most misses per unused entry are completed while slots are left.
-	const uint32_t hot_cap = std::min<uint32_t>(std::max<uint32_t>(opt.lds_slots, 2 * ncodes + 64), DfaImage::kMaxHot);
+	const uint32_t hot_cap = std::min<uint32_t>(std::max<uint32_t>(opt.lds_slots, 2 * ncr + 64), DfaImage::kMaxHot);
 	std::vector<uint32_t> nhot(S, 0), ncold(S, 0);
 	std::vector<uint64_t> w_miss(S, 0); // lookups of a row that miss
 	std::vector<uint8_t> is_d1(S, 0), klass(S, 0); // klass: 0 global array only, 1 complete in LDS, 2 partial in LDS
@@ -541,7 +563,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			}
 		return true;
 	};
-	const uint64_t hot_hi = hot_cap - ncodes; // an LDS row's base: every slot it can probe is below hot_cap
+	const uint64_t hot_hi = hot_cap - ncr; // an LDS row's base: every slot it can probe is below hot_cap
 	uint32_t n_sel = 0, n_demoted = 0;
 	for (uint32_t s : order) {
 		if (klass[s] == 0) continue;
@@ -566,7 +588,12 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 			for (uint64_t j = row_off[d1[c]]; j < row_off[d1[c] + 1]; j++) must[ent[j].target] = 1;
 		std::vector<uint32_t> rest;
 		for (uint32_t s = 1; s < S; s++)
-			if (!has_id[s] && (s >= N || reach[s])) rest.push_back(s);
+			if (!has_id[s] && (s >= N || reach[s])) {
+				// (failure form: a state is known by the ENTRY it was entered through, see the image below -- no base of its
+				// own is needed, and the states without slots in LDS all look their bytes up at cold_base, where nothing is)
+				if (fm) base_h[s] = cold_base, n_cold++;
+				else rest.push_back(s);
+			}
 		std::stable_sort(rest.begin(), rest.end(), [&](uint32_t a, uint32_t b) { return must[a] != must[b] ? must[a] > must[b] : w_row[a] > w_row[b]; });
 		for (uint32_t s : rest) {
 			const uint64_t b = H.fresh_base(1, hot_hi);
@@ -589,19 +616,19 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	for (uint32_t s = 1; s < S; s++) {
 		if (row_off[s + 1] == row_off[s]) continue;
 		place(G, s, false, hot_cap, 0, &base_g[s]);
-		if (G.max_used + ncodes + 1 > slot_limit) return fail("the automaton needs more slots than the limit");
+		if (G.max_used + ncr + 1 > slot_limit) return fail("the automaton needs more slots than the limit");
 	}
 	for (uint32_t s = 1; s < S; s++) // states without a row and without an LDS base: told apart by a global base that stores nothing
-		if (!has_id[s] && (s >= N || reach[s]) && row_off[s + 1] == row_off[s]) base_g[s] = (uint32_t)G.fresh_base(hot_cap, 0);
-	const uint64_t nslots = std::max<uint64_t>(std::max(G.max_used + 1, G.max_base + ncodes + 1), hot_cap); // base + any code is a readable slot
+		if (!fm && !has_id[s] && (s >= N || reach[s]) && row_off[s + 1] == row_off[s]) base_g[s] = (uint32_t)G.fresh_base(hot_cap, 0);
+	const uint64_t nslots = std::max<uint64_t>(std::max(G.max_used + 1, G.max_base + ncr + 1), hot_cap); // base + any code is a readable slot
 	if (nslots > slot_limit) return fail("the automaton needs more slots than the limit");
 	// An entry can be in LDS when its target has a base of its own (the others are only ever entered from
 	// the global array, which carries their global base); a row that leaves an entry out is a partial one.
-	auto stored = [&](uint32_t s, uint64_t j) { return (in_lds[s] == 1 || (in_lds[s] == 2 && sel[j] != 0)) && has_id[ent[j].target]; };
+	auto stored = [&](uint32_t s, uint64_t j) { return (in_lds[s] == 1 || (in_lds[s] == 2 && sel[j] != 0)) && (fm || has_id[ent[j].target]); };
 	std::vector<uint8_t> partial_row(S, 0);
 	for (uint32_t s = 1; s < S; s++) {
 		if (row_off[s + 1] == row_off[s]) {
-			partial_row[s] = !has_id[s];
+			partial_row[s] = !fm && !has_id[s]; // (failure form: no row, every lookup misses, rightly, at whatever base)
 			continue;
 		}
 		bool all = in_lds[s] == 1;
@@ -611,6 +638,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	pt.mark("placement (global)");
 	// ---- the image ----
 	out->ncodes = ncodes;
+	out->fail_code = fm ? failc : 0u;
 	out->stride = stride;
 	out->nslots = (uint32_t)nslots;
 	out->hot_slots = hot_cap;
@@ -618,14 +646,24 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	out->hot.assign(hot_cap, DfaImage::kEmptyWord);
 	out->slot.assign(2 * nslots, 0);
 	for (uint64_t i = 0; i < nslots; i++) out->slot[2 * i] = DfaImage::kEmptyWord;
-	out->gof.assign(hot_cap, 0);
+	out->gof.assign(fm ? nslots : hot_cap, 0);
 	out->ev_miss.assign(nslots, DfaImage::kEvNone);
 	out->ev_arr.assign(nslots, DfaImage::kEvNone);
 	out->ent_key.assign(nslots - hot_cap, DfaImage::kEvNone);
 	out->real_slots = out->virtual_slots = out->hot_used = 0;
 	// the word of a state: where its next byte is looked up
-	auto state_word = [&](uint32_t s) -> uint32_t { return base_h[s] | (partial_row[s] ? DfaImage::kPartial : 0u); };
-	for (uint32_t s = 1; s < S; s++) { // the states' keys
+	auto state_word = [&](uint32_t s) -> uint32_t {
+		return base_h[s] | (partial_row[s] ? DfaImage::kPartial : 0u) | (fm && f[s] == ROOT ? DfaImage::kRootFail : 0u);
+	};
+	// Failure form: the scan knows a state by the entry it arrived through (slot index T, either array; after a miss that
+	// consumed the byte: the root row's slot of the byte) -- every copy of an entry carries what is needed about its
+	// target: ev_miss[T] = F(target), gof[T] = the target's global base.  There are as many keys as slots, so the
+	// number of states is not limited by the values a 16-bit base can take, and any entry can be in LDS.
+	auto key_entry = [&](uint32_t t, uint32_t target) {
+		out->ev_miss[t] = M[target];
+		out->gof[t] = row_off[target + 1] != row_off[target] ? base_g[target] : 0u;
+	};
+	for (uint32_t s = 1; s < S && !fm; s++) { // the states' keys
 		if (s < N && !reach[s]) continue;
 		if (has_id[s]) {
 			out->ev_miss[base_h[s]] = M[s];
@@ -634,6 +672,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 	}
 	for (uint32_t c = 0; c < ncodes; c++) {
 		out->hot[c] = c << DfaImage::kLabelShift | state_word(d1[c]);
+		if (fm) key_entry(c, d1[c]);
 		out->real_slots++;
 		out->hot_used++;
 	}
@@ -655,6 +694,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 				const uint32_t t = base_h[s] + e.code;
 				out->hot[t] = word;
 				out->ev_arr[t] = e.arr;
+				if (fm) key_entry(t, e.target);
 				out->hot_used++;
 			}
 			{
@@ -662,6 +702,7 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 				out->slot[2 * (uint64_t)t] = word;
 				out->slot[2 * (uint64_t)t + 1] = base_g[e.target];
 				out->ev_arr[t] = e.arr;
+				if (fm) key_entry(t, e.target);
 				out->ent_key[t - hot_cap] = s << 8 | e.code;
 			}
 			if (e.virt) out->virtual_slots++;
@@ -691,32 +732,55 @@ void DfaRun(const DfaImage &img, const uint8_t *bytes, const uint64_t *off, uint
 	*total_tokens = 0;
 	std::vector<uint64_t> n_miss(img.ev_miss.size(), 0), n_arr(img.ev_arr.size(), 0);
 	uint32_t S = img.start_word(), G = 0;
+	uint32_t T = 0; // (failure form) the entry the state was entered through: the root row's slot of the separator at first
+	const bool fm = img.fail_code != 0;
 	uint64_t kind[4] = {0, 0, 0, 0}, steps = 0; // (trace) second looks: partial row miss / hit, no LDS base miss / hit
 	auto label = [&](uint32_t x) { return (x >> DfaImage::kLabelShift) & DfaImage::kLabelMask; };
 	for (uint64_t d = 0; d < D; d++) {
 		for (uint64_t p = off[d]; p <= off[d + 1]; p++) {
 			const uint32_t c = p < off[d + 1] ? img.code[ascii_lower(bytes[p])] : 0u;
-			steps++;
-			const uint32_t b = S & DfaImage::kBaseMask;
-			uint32_t id = b + c; // (always inside the LDS array)
-			uint32_t x = img.hot[id], g_next = G;
-			bool hit = label(x) == c;
-			if (!hit && (S & DfaImage::kPartial)) { // LDS does not hold this state's row completely: its copy in the global array decides
-				n_global++;
-				id = (b == img.cold_base ? G : img.gof[b]) + c;
-				x = img.slot[2 * (uint64_t)id];
-				hit = label(x) == c;
-				if (hit) g_next = img.slot[2 * (uint64_t)id + 1];
-				if (hit && global_hits) (*global_hits)[id - img.hot_slots]++;
-				kind[(b == img.cold_base ? 2 : 0) + (hit ? 1 : 0)]++;
-			}
-			if (hit) {
-				if (x & DfaImage::kArr) n_arr[id]++;
+			for (;;) { // (the failure form looks a byte up again in f's state; the flattened form takes every byte at once)
+				steps++;
+				const uint32_t b = S & DfaImage::kBaseMask;
+				// one lookup in the state's row: LDS first, the global array where LDS does not hold the row completely
+				auto look = [&](uint32_t code, uint32_t *id_out, uint32_t *x_out, uint32_t *g_out) -> bool {
+					uint32_t id = b + code; // (always inside the LDS array)
+					uint32_t x = img.hot[id];
+					bool hit = label(x) == code;
+					if (!hit && (S & DfaImage::kPartial)) {
+						n_global++;
+						id = (fm ? img.gof[T] : b == img.cold_base ? G : img.gof[b]) + code;
+						x = img.slot[2 * (uint64_t)id];
+						hit = label(x) == code;
+						if (hit) *g_out = img.slot[2 * (uint64_t)id + 1];
+						if (hit && global_hits) (*global_hits)[id - img.hot_slots]++;
+						kind[(b == img.cold_base ? 2 : 0) + (hit ? 1 : 0)]++;
+					}
+					*id_out = id, *x_out = x;
+					return hit;
+				};
+				uint32_t id, x, g_next = G;
+				if (look(c, &id, &x, &g_next)) {
+					if (x & DfaImage::kArr) n_arr[id]++;
+					S = x;
+					G = g_next;
+					T = id;
+					break;
+				}
+				n_miss[fm ? T : b == img.cold_base ? G : b]++;
+				if (!fm || (S & DfaImage::kRootFail)) {
+					S = c * img.stride | (fm ? DfaImage::kRootFail : 0u);
+					T = c;
+					break;
+				}
+				if (!look(img.fail_code, &id, &x, &g_next)) { // (cannot happen: every state whose f is not the root has the entry)
+					S = c * img.stride | DfaImage::kRootFail;
+					T = c;
+					break;
+				}
 				S = x;
 				G = g_next;
-			} else {
-				n_miss[b == img.cold_base ? G : b]++;
-				S = c * img.stride;
+				T = id;
 			}
 		}
 	}

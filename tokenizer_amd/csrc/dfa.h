@@ -48,6 +48,10 @@ struct DfaImage {
 	static constexpr uint32_t kLabelMask = 0xFFu;
 	static constexpr uint32_t kArr = 0x80000000u;
 	static constexpr uint32_t kPartial = 0x40000000u;
+	// (failure form only, see fail_code) the state's failure target is the root: a miss there consumes the byte
+	// and leads to the byte's depth-1 state, as every miss does in the flattened form
+	static constexpr uint32_t kRootFail = 0x20000000u;
+	static constexpr uint32_t kStateMask = 0xFFFFu | kPartial | kRootFail; // what of a word says which state it leads to
 	static constexpr uint32_t kBaseMask = 0xFFFFu;
 	static constexpr uint32_t kEmptyWord = 0xFF0000u;
 	static constexpr uint32_t kMaxCodes = 255;      // codes 0 .. ncodes - 1 in the label's byte, all ones = empty
@@ -84,6 +88,15 @@ struct DfaImage {
 	std::vector<uint32_t> pool;
 	uint8_t code[256] = {};
 	uint32_t ncodes = 0;  // code 0 = document separator, ncodes - 1 = every byte that labels no edge
+	// The FAILURE FORM (DfaOptions::fail_mode; 0 here = the flattened form above).  Rows hold the trie's own edges only,
+	// and f is followed explicitly: a miss in s emits F(s) alone (ev_miss[key] = F(s)) and leads to f(s) WITHOUT
+	// consuming the byte -- f(s)'s word is an entry of s's row under the pseudo-code fail_code = ncodes, which no
+	// corpus byte has -- unless f(s) is the root (kRootFail in every word that leads to s), where the byte is
+	// consumed and the next state is its depth-1 state.  No virtual entries, no arrivals: 1 + (trie nodes) * 2 slots
+	// at most whatever the vocabulary, and at most two lookups per byte on average (a failure pops what hits pushed)
+	// instead of one -- the form for vocabularies whose prefixes are mostly not tokens, whose flattened rows run
+	// into millions of virtual entries (kernels_dfa.hip: dfa_fscan_kernel).
+	uint32_t fail_code = 0;
 	uint32_t stride = 0;  // the row of the depth-1 state of code c starts at slot c * stride (row 0 = the root's)
 	uint32_t nslots = 0;
 	uint32_t real_slots = 0, virtual_slots = 0;
@@ -97,7 +110,7 @@ struct DfaImage {
 	bool valid = false;
 
 	// the state after a document separator: slot 0 (the root row is the separator's row)
-	uint32_t start_word() const { return hot.empty() ? 0u : hot[0] & (kBaseMask | kPartial); }
+	uint32_t start_word() const { return hot.empty() ? 0u : hot[0] & kStateMask; }
 	// share of the sample's lookups that `hot` alone answered
 	double hot_fraction() const;
 	// appends an event's ids to out (with repetitions)
@@ -119,6 +132,7 @@ struct DfaOptions {
 	// counts are taken over instead of running the sample again (40 ns per sample byte on the host)
 	const DfaImage *reuse = nullptr;
 	uint64_t vocab_tag = 0;
+	bool fail_mode = false;        // build the failure form (DfaImage::fail_code)
 };
 
 // ---- a batch of strings searched in one pass (tokscore_score_toggles) ------------------------------

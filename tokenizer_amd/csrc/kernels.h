@@ -239,6 +239,11 @@ struct DfaDev {
 	uint32_t hot_slots;      // keys and entries below it go to the streams, the others to counters
 	uint32_t cold_base;      // the LDS base of the states without one of their own
 	uint32_t stride;         // the depth-1 state of code c has its row at c * stride
+	// != 0: the image is in the failure form (dfa.h: DfaImage::fail_code) -- a state is known by the entry it was
+	// entered through (the second word of a range's entry / exit state is that slot index, gof and ev_miss are
+	// indexed by it and cover both arrays), a miss leads to the row's entry under this pseudo-code unless the
+	// state's word carries kRootFail.  Scanned by dfa_fscan_kernel.
+	uint32_t fail_code = 0;
 };
 struct DfaWork {
 	const uint2 *tcodes;     // the ranges' codes transposed (kernels_dfa.hip: dfa_transpose_kernel)

@@ -38,6 +38,7 @@ namespace {
 
 constexpr uint32_t kDfaBatchEntries = kStreamBatch * 512; // u16 entries of one stream batch (32 KiB)
 constexpr uint32_t kArr = 0x80000000u, kPartial = 0x40000000u, kBaseMask = 0xFFFFu, kLabelMask = 0xFFu, kLabelShift = 16; // (dfa.h: DfaImage)
+constexpr uint32_t kRootFail = 0x20000000u, kStateMask = kBaseMask | kPartial | kRootFail;
 constexpr uint32_t kEvNone = 0xFFFFFFFFu, kEvList = 0x80000000u;
 
 // One transition, as every path here takes it (the scan's loop in assembly does the same: tools/gen_dfa_asm.py).
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(256) dfa_transpose_kernel(const uint8_t *prep,
 // entry states of a new plan: the separator's state everywhere; cursors and fix-up words
 __global__ void __launch_bounds__(256) dfa_reset_states_kernel(uint2 *entry, uint32_t nranges, uint32_t start_word) {
 	for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < nranges; g += gridDim.x * blockDim.x)
-		entry[g] = uint2{start_word & (kBaseMask | kPartial), 0u};
+		entry[g] = uint2{start_word & kStateMask, 0u}; // (failure form: entered through slot 0, the root row's entry of the separator)
 }
 
 __global__ void __launch_bounds__(256) dfa_prepare_kernel(unsigned long long *out, uint32_t V, unsigned long long D,
@@ -227,6 +228,169 @@ __global__ void __launch_bounds__(1024) dfa_scan_kernel(DfaDev A, DfaWork W, Str
 	}
 	lm.close(Qm, lane);
 	la.close(Qa, lane);
+}
+
+// ---- the failure form (dfa.h: DfaImage::fail_code) ---------------------------------------------
+// For vocabularies whose prefixes are mostly not tokens (the reference annealer's own output,
+// /root/reference/src/tokenizer/TokenGenerator.cpp:190-217): their flattened rows run into millions of virtual
+// entries, so the image holds the trie's own edges and every state's failure entry instead, and f is
+// followed state by state -- a miss emits F(s) and leads to f(s) WITHOUT consuming the byte, unless f(s) is
+// the root.  That is 1.5 lookups per byte instead of one, and the lanes of a wave no longer take their bytes
+// at the same pace, so a lane keeps a window of its own: up to 16 bytes of its range in four registers, the
+// byte in front taken off by a shift.  The wave still loads in step -- piece p of every lane is appended once
+// every lane has room for it, a lane that is ahead runs on into the piece it already holds -- so the loads
+// stay whole cache lines of the transposed corpus, asked for a round early.
+//   A state is (word, T): T = the slot of the entry it was entered through, in either array.  Events are
+// keyed by T (stream for T in LDS, a counter beyond), the global copy of a state's row starts at gof[T].
+// LDS answers what it holds; a miss in a row that is not there completely, and a failure entry that is not
+// there, are looked up in the global array (L2) by the lanes concerned while the others wait.
+template <int C, bool HITS>
+__global__ void __launch_bounds__(1024) dfa_fscan_kernel(DfaDev A, DfaWork W, StreamDev Qm, StreamDev Qa, OutInit I, uint32_t dbg) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t dfa_f_smem[];
+	LDS_AS uint32_t *img = (LDS_AS uint32_t *)dfa_f_smem;
+	if (I.out) // (nothing else touches the output vector before this kernel has ended)
+		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < I.V + 5; i += gridDim.x * blockDim.x)
+			I.out[i] = i < 2 ? I.D : (i == I.V + 4 ? I.total_bytes : 0ull);
+	{
+		const u32x4 *src = reinterpret_cast<const u32x4 *>(A.hot);
+		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)img;
+		for (uint32_t i = threadIdx.x; i < (A.hot_slots + 3) / 4; i += blockDim.x) dst[i] = src[i]; // (the array is padded to 16 bytes)
+	}
+	__syncthreads();
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t wave = uni32(threadIdx.x >> 6);
+	const uint32_t waves = blockDim.x >> 6;
+	const uint32_t wave_id = blockIdx.x * waves + wave;
+	const uint32_t total_waves = gridDim.x * waves;
+	EventLog lm;
+	lm.open_own(Qm, wave_id);
+	if (lane == 0) Qa.fill[wave_id] = 0; // (no arrivals in this form: the wave's own batch of that stream stays empty)
+	const uint32_t pieces = uni32(W.range_bytes / 8);
+	const uint32_t hot_slots = A.hot_slots, stride = A.stride, failc = A.fail_code;
+	constexpr uint32_t kHigh = kDfaBatchEntries - C * 64 - 8;
+
+	const uint2 *gslot = A.slot;
+	const uint32_t *gof = A.gof;
+	auto label = [](uint32_t w) { return (w >> kLabelShift) & kLabelMask; };
+	for (uint32_t wb = wave_id; wb < W.nwb; wb += total_waves) {
+		// a range's state: word, T = the entry it was entered through, G = its row's global base while T is an entry of the
+		// global array; its window: w0 .. w3, `avail` bytes of the range from the low end of w0 on
+		uint32_t S[C], T[C], G[C], avail[C], w0[C], w1[C], w2[C], w3[C];
+		uint2 pre[C];
+		const uint2 *src = W.tcodes + (size_t)wb * pieces * C * 64 + lane;
+#pragma unroll
+		for (int j = 0; j < C; j++) {
+			const uint2 e = W.entry[(wb * C + j) * 64 + lane];
+			S[j] = e.x, T[j] = e.y;
+			G[j] = T[j] >= hot_slots ? gof[T[j]] : 0u;
+			const uint2 p0 = src[(size_t)j * 64];
+			w0[j] = p0.x, w1[j] = p0.y, w2[j] = w3[j] = 0, avail[j] = 8;
+			pre[j] = pieces > 1 ? src[((size_t)C + j) * 64] : uint2{0u, 0u};
+		}
+		uint32_t next = 1; // the piece in `pre`
+		for (;;) {
+			const bool more = next < pieces; // (uniform)
+			const uint32_t th = more ? 8u : 0u;
+			// until every range of every lane has room for the next piece (has taken all its bytes, at the end)
+			for (;;) {
+				bool any = false;
+#pragma unroll
+				for (int j = 0; j < C; j++) any = any || avail[j] > th;
+				if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+				// One step of every range, in stages: what LDS says for all of them, then the global array's answers for
+				// all of them in ONE round trip (the loads of the C ranges are under way together), then the outcome.
+				// No branch per range: a lane that needs nothing from the global array reads its slot 0 (one line for
+				// all such lanes) and drops it.
+				uint32_t c[C], id[C], idf[C], x[C], xf[C];
+				bool act[C], hit[C], cold[C], cold_f[C];
+				bool any_cold = false;
+#pragma unroll
+				for (int j = 0; j < C; j++) {
+					c[j] = w0[j] & 0xFFu;
+					const uint32_t b = S[j] & kBaseMask;
+					id[j] = b + c[j], idf[j] = b + failc; // (both inside the LDS array)
+					x[j] = img[id[j]], xf[j] = img[idf[j]];
+				}
+#pragma unroll
+				for (int j = 0; j < C; j++) {
+					act[j] = avail[j] != 0;
+					hit[j] = label(x[j]) == c[j];
+					// LDS does not hold the row completely: its global copy decides -- the byte's slot and, for a state
+					// whose failure entry LDS does not hold either, that entry's, asked for together
+					cold[j] = act[j] && !hit[j] && (S[j] & kPartial) != 0;
+					cold_f[j] = cold[j] && (S[j] & kRootFail) == 0 && label(xf[j]) != failc;
+					any_cold = any_cold || cold[j];
+				}
+				if (!(dbg & 4) && __builtin_amdgcn_ballot_w64(any_cold) != 0) {
+					uint32_t g[C];
+					uint2 w[C], wf[C];
+#pragma unroll
+					for (int j = 0; j < C; j++) { // the row's global base: came with the entry when that was a global one, else gof[T]
+						const bool need = cold[j] && T[j] < hot_slots;
+						const uint32_t gl = gof[need ? T[j] : 0u];
+						g[j] = need ? gl : G[j];
+					}
+#pragma unroll
+					for (int j = 0; j < C; j++) {
+						w[j] = gslot[cold[j] ? g[j] + c[j] : 0u];
+						wf[j] = gslot[cold_f[j] ? g[j] + failc : 0u];
+					}
+#pragma unroll
+					for (int j = 0; j < C; j++) {
+						const bool ghit = cold[j] && label(w[j].x) == c[j];
+						const bool usef = cold_f[j] && !ghit;
+						x[j] = ghit ? w[j].x : x[j], id[j] = ghit ? g[j] + c[j] : id[j];
+						hit[j] = hit[j] || ghit;
+						xf[j] = usef ? wf[j].x : xf[j], idf[j] = usef ? g[j] + failc : idf[j];
+						G[j] = ghit ? w[j].y : usef ? wf[j].y : G[j];
+						if (HITS) {
+							if (ghit || usef) atomicAdd(&W.cold_hit[(ghit ? id[j] : idf[j]) - hot_slots], 1u);
+						}
+					}
+				}
+#pragma unroll
+				for (int j = 0; j < C; j++) {
+					const bool miss = act[j] && !hit[j];
+					const bool root = (S[j] & kRootFail) != 0;
+					if (!(dbg & 2)) lm.put(miss && T[j] < hot_slots, T[j]);
+					if (!(dbg & 1) && miss && T[j] >= hot_slots) atomicAdd(&W.cold_miss[T[j] - hot_slots], 1u);
+					const uint32_t s_new = hit[j] ? x[j] : root ? (c[j] * stride | kRootFail) : xf[j];
+					const uint32_t t_new = hit[j] ? id[j] : root ? c[j] : idf[j];
+					S[j] = act[j] ? s_new : S[j];
+					T[j] = act[j] ? t_new : T[j];
+					const uint32_t n = act[j] && (hit[j] || root) ? 1u : 0u; // the byte is taken, or stays for f's state
+					w0[j] = __builtin_amdgcn_alignbyte(w1[j], w0[j], n);
+					w1[j] = __builtin_amdgcn_alignbyte(w2[j], w1[j], n);
+					w2[j] = __builtin_amdgcn_alignbyte(w3[j], w2[j], n);
+					w3[j] = __builtin_amdgcn_alignbyte(0u, w3[j], n);
+					avail[j] -= n;
+				}
+				if (lm.cur > kHigh) lm.roll(Qm, lane);
+			}
+			if (!more) break;
+#pragma unroll
+			for (int j = 0; j < C; j++) { // avail <= 8: the piece goes behind what is left
+				const unsigned long long p = (unsigned long long)pre[j].y << 32 | pre[j].x;
+				unsigned long long lo = (unsigned long long)w1[j] << 32 | w0[j], hi;
+				const uint32_t sh = 8 * avail[j];
+				if (avail[j] == 8) hi = p;
+				else {
+					lo |= p << sh;
+					hi = sh ? p >> (64 - sh) : 0ull;
+				}
+				w0[j] = (uint32_t)lo, w1[j] = (uint32_t)(lo >> 32), w2[j] = (uint32_t)hi, w3[j] = (uint32_t)(hi >> 32);
+				avail[j] += 8;
+			}
+			next++;
+			if (next < pieces) {
+#pragma unroll
+				for (int j = 0; j < C; j++) pre[j] = src[((size_t)next * C + j) * 64];
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < C; j++) W.exit_a[(wb * C + j) * 64 + lane] = uint2{S[j] & kStateMask, T[j]};
+	}
+	lm.close(Qm, lane);
 }
 
 // ---- the scan's loop, hand-written for gfx950 -------------------------------------------------
@@ -589,10 +753,42 @@ struct DfaFix {
 // Two range boundaries' states are the same when their words are and, under cold_base, their global bases (the
 // global base a lane carries outside cold_base is whatever it last loaded: it says nothing)
 __device__ __forceinline__ bool dfa_same_state(const DfaDev &A, uint2 a, uint2 b) {
+	if (A.fail_code) return a.y == b.y; // (failure form: entered through the same entry -- the word follows from it)
 	return a.x == b.x && ((a.x & kBaseMask) != A.cold_base || a.y == b.y);
 }
 
+// the failure form's step, until the byte is taken (G is T here: the entry the state was entered through)
+__device__ void dfa_step_global_fail(const DfaFix &F, uint32_t &S, uint32_t &T, uint32_t c, long long sign) {
+	const DfaDev &A = F.A;
+	for (;;) {
+		const uint32_t b = S & kBaseMask;
+		uint32_t id = b + c, x = A.hot[id];
+		bool hit = ((x >> kLabelShift) & kLabelMask) == c;
+		if (!hit && (S & kPartial)) {
+			id = A.gof[T] + c;
+			x = A.slot[id].x;
+			hit = ((x >> kLabelShift) & kLabelMask) == c;
+		}
+		if (hit) {
+			S = x & kStateMask, T = id;
+			return;
+		}
+		book_event(A, A.ev_miss[T], sign, F.out, F.total_index);
+		if (S & kRootFail) {
+			S = c * A.stride | kRootFail, T = c;
+			return;
+		}
+		id = b + A.fail_code, x = A.hot[id];
+		if (((x >> kLabelShift) & kLabelMask) != A.fail_code) {
+			id = A.gof[T] + A.fail_code;
+			x = A.slot[id].x;
+		}
+		S = x & kStateMask, T = id;
+	}
+}
+
 __device__ __forceinline__ void dfa_step_global(const DfaFix &F, uint32_t &S, uint32_t &G, uint32_t c, long long sign) {
+	if (F.A.fail_code) return dfa_step_global_fail(F, S, G, c, sign);
 	DfaStep r = dfa_step(F.A, F.A.hot, S, G, c);
 	if (r.second_look) dfa_second_look(F.A, r, S, G, c);
 	if (r.hit) {
@@ -608,9 +804,9 @@ __device__ __forceinline__ void dfa_step_global(const DfaFix &F, uint32_t &S, ui
 // true when the two automata met inside the range (its exit stands); *exit_out = the true one's state at the end.
 // (Two states are the same when their words are and, under cold_base, their global bases.)
 __device__ bool dfa_dual_walk(const DfaFix &F, uint32_t g, uint2 want, uint2 have, uint2 *exit_out) {
-	const uint32_t keep = kBaseMask | kPartial;
+	const uint32_t keep = kStateMask;
 	uint32_t Sa = want.x & keep, Ga = want.y, Sb = have.x & keep, Gb = have.y;
-	auto same = [&]() { return Sa == Sb && ((Sa & kBaseMask) != F.A.cold_base || Ga == Gb); };
+	auto same = [&]() { return F.A.fail_code ? Ga == Gb : Sa == Sb && ((Sa & kBaseMask) != F.A.cold_base || Ga == Gb); };
 	const uint8_t *p = F.codes + (size_t)g * F.range_bytes;
 	for (uint32_t i = 0; i < F.range_bytes; i++) {
 		if (same()) return true;
@@ -899,6 +1095,49 @@ __global__ void __launch_bounds__(1024) dfa_reduce_kernel(DfaDev A, const int16_
 
 __global__ void __launch_bounds__(256) dfa_fixup_kernel(DfaFix F) { dfa_fixup_body(F); }
 
+// The counters of the global array's keys through the event tables, for the failure form: there a few percent of
+// an evaluation's events are counted under such keys (a state entered through an entry LDS does not hold), by a
+// hundred thousand counters whose events name the same few thousand ids -- booked one by one (dfa_reduce_kernel's
+// last workgroups) they queue on those ids' words, 0.34 ms per evaluation.  Here a workgroup adds its counters'
+// events up in LDS bins over the ids first and books every id once.
+__global__ void __launch_bounds__(1024) dfa_reduce_cold_kernel(DfaDev A, uint32_t *cold_miss, uint32_t *cold_arr, uint32_t n_ids,
+                                                               unsigned long long *out, uint32_t total_index) {
+	extern __shared__ __attribute__((aligned(16))) uint32_t cold_bins[];
+	for (uint32_t i = threadIdx.x; i < n_ids; i += blockDim.x) cold_bins[i] = 0;
+	__syncthreads();
+	auto add = [&](uint32_t ev, uint32_t n) {
+		if (ev == kEvNone) return;
+		if (!(ev & kEvList)) {
+			atomicAdd(&cold_bins[ev], n);
+			return;
+		}
+		const uint32_t o = ev & ~kEvList, len = A.pool[o];
+		for (uint32_t i = 0; i < len; i++) atomicAdd(&cold_bins[A.pool[o + 1 + i]], n);
+	};
+	const uint32_t n = A.nslots - A.hot_slots;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		const uint32_t m = cold_miss[i], a = cold_arr[i];
+		if (m) {
+			add(A.ev_miss[A.hot_slots + i], m);
+			cold_miss[i] = 0;
+		}
+		if (a) {
+			add(A.ev_arr[A.hot_slots + i], a);
+			cold_arr[i] = 0;
+		}
+	}
+	__syncthreads();
+	long long mine = 0;
+	for (uint32_t i = threadIdx.x; i < n_ids; i += blockDim.x) {
+		const uint32_t v = cold_bins[i];
+		if (v) {
+			atomicAdd(&out[i], (unsigned long long)v);
+			mine += v;
+		}
+	}
+	add_block_total(mine, out, total_index);
+}
+
 } // namespace
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -939,7 +1178,32 @@ void launch_dfa_scan(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, con
 		const char *e = getenv("TOKSCORE_ASM");
 		return !(e && atoi(e) == 0);
 	}();
-	if (use_asm) {
+	if (A.fail_code) { // the failure form: lanes with windows of their own (W.cold_hit: null once the layout has its counts)
+		// (dbg: timing experiments, results wrong -- 1 no counters for the global array's keys, 2 no event log, 4 no global
+		// lookups; tools/dbg/fail_dbg.sh.  Measured at 100 MB on the annealed vocabulary: 0.65 ms as it is, 0.53 / 0.62 / 0.31
+		// without each, 0.21 without all three = the loop itself)
+		const uint32_t dbg = getenv("TOKSCORE_FSCAN_DBG") ? (uint32_t)atoi(getenv("TOKSCORE_FSCAN_DBG")) : 0u;
+		auto go = [&](auto kernel) {
+			(void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan.lds_bytes);
+			if (ev_start && ev_stop)
+				hipExtLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, ev_start, ev_stop,
+				                      0u, A, W, Qm, Qa, init, dbg);
+			else hipLaunchKernelGGL(kernel, dim3(plan.blocks), dim3(64 * plan.waves_per_block), plan.lds_bytes, stream, A, W, Qm, Qa, init, dbg);
+		};
+		if (W.cold_hit) {
+			switch (plan.chains) {
+			case 1: go(&dfa_fscan_kernel<1, true>); break;
+			case 2: go(&dfa_fscan_kernel<2, true>); break;
+			default: go(&dfa_fscan_kernel<4, true>); break;
+			}
+		} else {
+			switch (plan.chains) {
+			case 1: go(&dfa_fscan_kernel<1, false>); break;
+			case 2: go(&dfa_fscan_kernel<2, false>); break;
+			default: go(&dfa_fscan_kernel<4, false>); break;
+			}
+		}
+	} else if (use_asm) {
 		switch (plan.chains) {
 		case 1: go(&dfa_scan_asm_kernel<1>); break;
 		case 2: go(&dfa_scan_asm_kernel<2>); break;
@@ -969,9 +1233,17 @@ void launch_dfa_count(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, co
 	                   total_index);
 	const uint32_t colgroups = (A.hot_slots + 127) / 128;
 	const uint32_t ncold = A.nslots - A.hot_slots;
-	const uint32_t coldblocks = std::min<uint32_t>((ncold + 1023) / 1024, 256);
+	// (the failure form counts a share of its events under keys of the global array: a launch of its own adds them up in LDS first)
+	const bool cold_apart = A.fail_code != 0 && ncold != 0 && (uint64_t)total_index * 4 <= 150u * 1024;
+	const uint32_t coldblocks = cold_apart ? 0u : std::min<uint32_t>((ncold + 1023) / 1024, 256);
 	hipLaunchKernelGGL(dfa_reduce_kernel, dim3(colgroups + coldblocks), dim3(64 * kDfaReduceGroups), 0, stream, A, rows, miss_blocks,
 	                   miss_blocks + arrival_blocks, colgroups, W.cold_miss, W.cold_arr, Qm, Qa, first_batches, changed, out, total_index);
+	if (cold_apart) {
+		const uint32_t lds_cold = total_index * 4;
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dfa_reduce_cold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cold);
+		hipLaunchKernelGGL(dfa_reduce_cold_kernel, dim3(std::min<uint32_t>((ncold + 4095) / 4096, 64)), dim3(1024), lds_cold, stream, A, W.cold_miss,
+		                   W.cold_arr, total_index, out, total_index);
+	}
 }
 
 void launch_stream_blocks(const uint32_t *pbeg, uint32_t nstreams, uint32_t prep_total, uint32_t *block_stream, hipStream_t stream) {

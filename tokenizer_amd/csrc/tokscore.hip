@@ -261,6 +261,13 @@ struct tokscore_ctx {
 	// the automaton serves a vocabulary while the sample's lookups beyond LDS and its arrivals on virtual entries stay
 	// below these shares (parts per million; TOKSCORE_DFA_MAX_COLD_PPM, TOKSCORE_DFA_MAX_VIRTUAL_PPM)
 	uint64_t dfa_max_cold_ppm = 10000, dfa_max_virtual_ppm = 30000;
+	// the failure form (dfa.h: DfaImage::fail_code; kernels_dfa.hip: dfa_fscan_kernel) for the vocabularies the policy
+	// above turns away: taken while its own sample sends at most this share of the lookups beyond LDS
+	// (TOKSCORE_DFA_FAIL_MAX_COLD_PPM).  TOKSCORE_DFA_FORM: 0 = as the samples say, 1 = flattened or nothing, 2 = the
+	// failure form whatever the vocabulary.
+	uint64_t dfa_fail_max_cold_ppm = 300000; // (measured: wiki_annealed 0.18 - 0.28 wins over the tile scan, random UTF-8 V = 128 k 0.38 loses)
+	uint32_t dfa_form_knob = 0;
+	bool dfa_fail = false;         // the image is in the failure form
 	DfaScanPlan dplan = {};
 	uint32_t *d_dhot = nullptr, *d_dgof = nullptr, *d_dslot = nullptr, *d_dev_miss = nullptr, *d_dev_arr = nullptr, *d_dpool = nullptr;
 	uint8_t *d_dcodes = nullptr;   // the prepared corpus in the automaton's codes, linear
@@ -887,6 +894,7 @@ bool upload_dfa_image(tokscore_ctx *c) {
 	opt.sample = c->sample.empty() ? nullptr : c->sample.data();
 	opt.sample_bytes = c->sample.size();
 	opt.corpus_bytes = c->total + c->D;
+	opt.fail_mode = c->dfa_fail;
 	c->dfa_prior_keys.clear(), c->dfa_prior_counts.clear();
 	for (const auto &kv : c->dfa_prior) c->dfa_prior_keys.push_back(kv.first), c->dfa_prior_counts.push_back(kv.second);
 	if (!c->dfa_prior.empty()) opt.prior_keys = c->dfa_prior_keys.data(), opt.prior_counts = c->dfa_prior_counts.data(), opt.prior_n = c->dfa_prior.size();
@@ -895,25 +903,25 @@ bool upload_dfa_image(tokscore_ctx *c) {
 	// (a new image object each time: the old one lends its sample counts while the vocabulary is what it was built from)
 	DfaImage fresh;
 	opt.vocab_tag = c->toggle_version + 1;
-	if (c->dimg.valid) opt.reuse = &c->dimg;
+	if (c->dimg.valid && (c->dimg.fail_code != 0) == c->dfa_fail) opt.reuse = &c->dimg;
 	if (!c->trie.BuildDfa(&fresh, opt, &why)) return false;
 	c->dimg = std::move(fresh);
 	c->dfa_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 	const DfaImage &g = c->dimg;
-	const size_t n = g.nslots, nh = g.hot_slots, ne = g.ev_miss.size();
+	const size_t n = g.nslots, nh = g.hot_slots, ne = g.ev_miss.size(), ng = g.gof.size();
 	for (uint32_t **b : {&c->d_dhot, &c->d_dgof, &c->d_dslot, &c->d_dev_miss, &c->d_dev_arr, &c->d_dpool}) {
 		if (*b) (void)hipFree(*b);
 		*b = nullptr;
 	}
 	bool ok = hipMalloc((void **)&c->d_dhot, (nh + 16) * sizeof(uint32_t)) == hipSuccess &&
-	          hipMalloc((void **)&c->d_dgof, (nh + 16) * sizeof(uint32_t)) == hipSuccess &&
+	          hipMalloc((void **)&c->d_dgof, (ng + 16) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dslot, (2 * n + 16) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dev_miss, (ne + 16) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dev_arr, (ne + 16) * sizeof(uint32_t)) == hipSuccess &&
 	          hipMalloc((void **)&c->d_dpool, (g.pool.size() + 16) * sizeof(uint32_t)) == hipSuccess;
 	ok = ok && hipMemsetAsync(c->d_dhot + nh, 0xFF, 16 * sizeof(uint32_t), c->stream) == hipSuccess &&
 	     hipMemcpyAsync(c->d_dhot, g.hot.data(), nh * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-	     hipMemcpyAsync(c->d_dgof, g.gof.data(), nh * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+	     hipMemcpyAsync(c->d_dgof, g.gof.data(), ng * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
 	     hipMemcpyAsync(c->d_dslot, g.slot.data(), 2 * n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
 	     hipMemcpyAsync(c->d_dev_miss, g.ev_miss.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
 	     hipMemcpyAsync(c->d_dev_arr, g.ev_arr.data(), ne * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess &&
@@ -930,6 +938,7 @@ DfaDev dfa_dev(const tokscore_ctx *c) {
 	A.hot_slots = c->dimg.hot_slots;
 	A.cold_base = c->dimg.cold_base;
 	A.stride = c->dimg.stride;
+	A.fail_code = c->dimg.fail_code;
 	return A;
 }
 
@@ -946,6 +955,9 @@ DfaWork dfa_work(const tokscore_ctx *c) {
 	W.cold_miss = c->d_dcold;
 	W.cold_arr = c->d_dcold + c->dimg.nslots + 1;
 	W.cold_hit = c->d_dcold + 2 * ((size_t)c->dimg.nslots + 1);
+	// (the failure form sends a share of its lookups to the global array by design: their hits are counted only while
+	// a re-layout can still use them)
+	if (c->dfa_fail && !(c->dfa_relayout_on && c->dfa_relayouts < c->dfa_relayouts_max)) W.cold_hit = nullptr;
 	return W;
 }
 
@@ -957,8 +969,13 @@ void ensure_dfa(tokscore_ctx *c) {
 	const uint64_t prep_total = c->total + c->D;
 	if (!c->dfa_enabled || c->force_generic || c->D == 0 || c->total == 0 || c->V + 5 >= 0x7FFFFFFFull || prep_total + kCorpusPad >= 0xFFFF0000ull) return;
 	const auto t0 = std::chrono::steady_clock::now();
-	if (!upload_dfa_image(c)) return;
-	{
+	c->dfa_fail = c->dfa_form_knob == 2;
+	if (!upload_dfa_image(c)) {
+		if (c->dfa_fail || c->dfa_form_knob == 1) return;
+		c->dfa_fail = true; // (more virtual entries than the limit: the failure form has none)
+		if (!upload_dfa_image(c)) return;
+	}
+	if (!c->dfa_fail) {
 		// The automaton pays off while LDS answers nearly every lookup and arrivals on virtual entries are rare (the
 		// loop keeps both behind one rarely taken branch).  A vocabulary whose tokens' prefixes are mostly not tokens
 		// (the reference annealer's own output: a third of the steps arrive on a virtual entry, almost half need the
@@ -966,10 +983,19 @@ void ensure_dfa(tokscore_ctx *c) {
 		const DfaImage &g = c->dimg;
 		const double steps = (double)std::max<uint64_t>(1, g.sample_steps);
 		const double limit_cold = (double)c->dfa_max_cold_ppm * 1e-6, limit_virtual = (double)c->dfa_max_virtual_ppm * 1e-6;
-		if (g.sample_steps != 0 && ((double)g.sample_cold / steps > limit_cold || (double)g.sample_virtual / steps > limit_virtual)) return;
+		if (g.sample_steps != 0 && ((double)g.sample_cold / steps > limit_cold || (double)g.sample_virtual / steps > limit_virtual)) {
+			if (c->dfa_form_knob == 1) return;
+			c->dfa_fail = true;
+			if (!upload_dfa_image(c)) return;
+		}
+	}
+	if (c->dfa_fail && c->dfa_form_knob != 2) {
+		const DfaImage &g = c->dimg;
+		if (g.sample_steps != 0 && (double)g.sample_cold / (double)g.sample_steps > (double)c->dfa_fail_max_cold_ppm * 1e-6) return;
 	}
 	DfaScanPlan &P = c->dplan;
-	if (!plan_dfa_scan(c->dimg.hot_slots, prep_total, (uint32_t)c->num_cus, c->dfa_chains, &P)) return;
+	// (the failure form waits for the global array in most steps: four ranges per lane share each wait)
+	if (!plan_dfa_scan(c->dimg.hot_slots, prep_total, (uint32_t)c->num_cus, c->dfa_fail && c->dfa_chains == 0 ? 4 : c->dfa_chains, &P)) return;
 	const uint64_t nranges = (uint64_t)P.nwb * 64 * P.chains;
 	const uint64_t covered = nranges * P.range_bytes; // >= prep_total: the rest reads as separators
 	const uint64_t lin_bytes = std::max<uint64_t>(covered, prep_total) + kCorpusPad;
@@ -1571,6 +1597,8 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->fix_epoch_wrapped = c->fix_epoch != 0;
 	c->dfa_max_cold_ppm = env_u64("TOKSCORE_DFA_MAX_COLD_PPM", c->dfa_max_cold_ppm);
 	c->dfa_max_virtual_ppm = env_u64("TOKSCORE_DFA_MAX_VIRTUAL_PPM", c->dfa_max_virtual_ppm);
+	c->dfa_fail_max_cold_ppm = env_u64("TOKSCORE_DFA_FAIL_MAX_COLD_PPM", c->dfa_fail_max_cold_ppm);
+	c->dfa_form_knob = (uint32_t)env_u64("TOKSCORE_DFA_FORM", 0);
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
@@ -2587,6 +2615,7 @@ int tokscore_get_info(tokscore_ctx *c, tokscore_info *info) {
 		info->dfa_plan_ms = c->dfa_plan_ms;
 		info->dfa_second_hits = c->dfa_second_hits;
 		info->dfa_relayouts = c->dfa_relayouts;
+		info->dfa_form = c->dfa_fail ? 2u : 1u;
 		if (c->dfa_used_last) info->scan_path = 2;
 	}
 	return TOKSCORE_OK;
@@ -2674,6 +2703,7 @@ int tokscore_hostdfa_check(tokscore_ctx *c, const uint8_t *bytes, const uint64_t
 	if (lds_slots) opt.lds_slots = lds_slots;
 	opt.sample = bytes ? bytes + off[0] : nullptr;
 	opt.sample_bytes = std::min<uint64_t>(off[D] - off[0], kSampleBytes);
+	opt.fail_mode = env_u64("TOKSCORE_HOSTDFA_FAIL", 0) != 0; // the failure form (dfa.h: DfaImage::fail_code) instead of the flattened one
 	std::string why;
 	if (!c->trie.BuildDfa(&img, opt, &why)) return fail(c, TOKSCORE_E_VOCAB, why);
 	uint64_t global_reads = 0;
