@@ -226,6 +226,8 @@ bool VocabTrie::BuildDfa(DfaImage *out, const DfaOptions &opt, std::string *why)
 				}
 			}
 			if (ent.size() > budget) return fail("the automaton needs more slots than the limit");
+			if (!fm && opt.max_virtual_per_node && ent.size() > (uint64_t)N * (1 + opt.max_virtual_per_node))
+				return fail("more virtual entries per trie node than the caller takes");
 			std::sort(ent.begin() + (std::ptrdiff_t)row_off[s], ent.end(), [](const Entry &a, const Entry &b) { return a.code < b.code; });
 		}
 		row_off[S] = ent.size();

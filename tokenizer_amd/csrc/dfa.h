@@ -133,6 +133,9 @@ struct DfaOptions {
 	const DfaImage *reuse = nullptr;
 	uint64_t vocab_tag = 0;
 	bool fail_mode = false;        // build the failure form (DfaImage::fail_code)
+	// flattened form only, 0 = no limit: give up as soon as the rows hold more than this many virtual entries per trie
+	// node (the caller would turn such an image away anyway: what the reference's annealer writes has 23)
+	uint32_t max_virtual_per_node = 0;
 };
 
 // ---- a batch of strings searched in one pass (tokscore_score_toggles) ------------------------------

@@ -1029,7 +1029,7 @@ constexpr uint32_t kDfaReduceGroups = 16;
 __global__ void __launch_bounds__(1024) dfa_reduce_kernel(DfaDev A, const int16_t *slab, uint32_t split, uint32_t rows, uint32_t colgroups,
                                                           uint32_t *cold_miss, uint32_t *cold_arr, StreamDev Qm, StreamDev Qa,
                                                           uint32_t first_batches, uint32_t *changed, unsigned long long *out,
-                                                          uint32_t total_index) {
+                                                          uint32_t total_index, uint32_t defer) {
 	__shared__ int part[kDfaReduceGroups][64][4];
 #ifdef DFA_EXP_RED1
 	if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -1088,7 +1088,13 @@ __global__ void __launch_bounds__(1024) dfa_reduce_kernel(DfaDev A, const int16_
 		const uint32_t q = grp, key = k + (q & 1u);
 		int sum = 0;
 		for (uint32_t g = 0; g < kDfaReduceGroups; g++) sum += part[g][lane][q];
-		if (sum != 0 && key < width) mine = book_event_ids(A, (q < 2 ? A.ev_miss : A.ev_arr)[key], sum, out);
+		if (sum != 0 && key < width) {
+			// (defer: the failure form's keys name the same few thousand ids tens of thousands of times -- their sums go
+			// behind the global array's counters, cold_miss / cold_arr[nslots - width + key], and dfa_reduce_cold_kernel
+			// books all of them through LDS bins over the ids)
+			if (defer) (q < 2 ? cold_miss : cold_arr)[A.nslots - width + key] = (uint32_t)sum;
+			else mine = book_event_ids(A, (q < 2 ? A.ev_miss : A.ev_arr)[key], sum, out);
+		}
 	}
 	add_block_total(mine, out, total_index);
 }
@@ -1114,15 +1120,18 @@ __global__ void __launch_bounds__(1024) dfa_reduce_cold_kernel(DfaDev A, uint32_
 		const uint32_t o = ev & ~kEvList, len = A.pool[o];
 		for (uint32_t i = 0; i < len; i++) atomicAdd(&cold_bins[A.pool[o + 1 + i]], n);
 	};
-	const uint32_t n = A.nslots - A.hot_slots;
+	// counters [0, nslots - hot_slots): the global array's keys hot_slots + i; behind them the sums of the LDS keys
+	// that dfa_reduce_kernel left there
+	const uint32_t n = A.nslots, n_cold = A.nslots - A.hot_slots;
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
 		const uint32_t m = cold_miss[i], a = cold_arr[i];
+		const uint32_t key = i < n_cold ? A.hot_slots + i : i - n_cold;
 		if (m) {
-			add(A.ev_miss[A.hot_slots + i], m);
+			add(A.ev_miss[key], m);
 			cold_miss[i] = 0;
 		}
 		if (a) {
-			add(A.ev_arr[A.hot_slots + i], a);
+			add(A.ev_arr[key], a);
 			cold_arr[i] = 0;
 		}
 	}
@@ -1237,11 +1246,12 @@ void launch_dfa_count(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, co
 	const bool cold_apart = A.fail_code != 0 && ncold != 0 && (uint64_t)total_index * 4 <= 150u * 1024;
 	const uint32_t coldblocks = cold_apart ? 0u : std::min<uint32_t>((ncold + 1023) / 1024, 256);
 	hipLaunchKernelGGL(dfa_reduce_kernel, dim3(colgroups + coldblocks), dim3(64 * kDfaReduceGroups), 0, stream, A, rows, miss_blocks,
-	                   miss_blocks + arrival_blocks, colgroups, W.cold_miss, W.cold_arr, Qm, Qa, first_batches, changed, out, total_index);
+	                   miss_blocks + arrival_blocks, colgroups, W.cold_miss, W.cold_arr, Qm, Qa, first_batches, changed, out, total_index,
+	                   cold_apart ? 1u : 0u);
 	if (cold_apart) {
 		const uint32_t lds_cold = total_index * 4;
 		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dfa_reduce_cold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cold);
-		hipLaunchKernelGGL(dfa_reduce_cold_kernel, dim3(std::min<uint32_t>((ncold + 4095) / 4096, 64)), dim3(1024), lds_cold, stream, A, W.cold_miss,
+		hipLaunchKernelGGL(dfa_reduce_cold_kernel, dim3(std::min<uint32_t>((A.nslots + 4095) / 4096, 64)), dim3(1024), lds_cold, stream, A, W.cold_miss,
 		                   W.cold_arr, total_index, out, total_index);
 	}
 }

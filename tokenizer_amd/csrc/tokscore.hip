@@ -895,6 +895,9 @@ bool upload_dfa_image(tokscore_ctx *c) {
 	opt.sample_bytes = c->sample.size();
 	opt.corpus_bytes = c->total + c->D;
 	opt.fail_mode = c->dfa_fail;
+	// (a flattened image of that shape is turned away by ensure_dfa's policy: not built in the first place, unless the
+	// policy is lifted or that form is asked for)
+	if (c->dfa_form_knob != 1 && c->dfa_max_virtual_ppm < 1000000) opt.max_virtual_per_node = 8;
 	c->dfa_prior_keys.clear(), c->dfa_prior_counts.clear();
 	for (const auto &kv : c->dfa_prior) c->dfa_prior_keys.push_back(kv.first), c->dfa_prior_counts.push_back(kv.second);
 	if (!c->dfa_prior.empty()) opt.prior_keys = c->dfa_prior_keys.data(), opt.prior_counts = c->dfa_prior_counts.data(), opt.prior_n = c->dfa_prior.size();
