@@ -352,8 +352,8 @@ def annealed_vocab_block(dev, args, synth, ta):
     """Not the headline: the same measurement with the vocabulary the REFERENCE's own annealer wrote
     (tests/golden/wiki_annealed/tokens.json.gz: 30,275 tokens, 124,789 trie nodes, most prefixes not tokens) on
     --mb MB of the kind of text it was annealed on (synth.wiki_like seed 1234, 20,000 words), checked against the
-    C restatement on the whole shard.  A vocabulary of that shape does not suit the automaton scan (tokscore.hip:
-    ensure_dfa); the plan's own scan serves it."""
+    C restatement on the whole shard.  A vocabulary of that shape does not suit the flattened automaton (2.8 M virtual
+    entries); the library takes the automaton's failure form for it (dfa.h: DfaImage::fail_code, dfa_fscan_kernel)."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ffi as O
@@ -387,7 +387,8 @@ def annealed_vocab_block(dev, args, synth, ta):
         alg = int(info.corpus_bytes) + 8 * (V + 3)
         return {"value": len(corpus) * n / dt / 1e9, "unit": "GB/s", "ms_per_step": dt / n * 1e3, "steps": n,
                 "vocab": V, "trie_nodes": int(info.trie_nodes), "bytes": int(info.corpus_bytes), "total_tokens": int(got[V + 3]),
-                "scan_path": "lds_automaton" if info.dfa_active else {1: "lds_tile", 2: "lds_stream"}.get(int(info.scan_path), "generic"),
+                "scan_path": ("lds_automaton_failure_form" if info.dfa_form == 2 else "lds_automaton") if info.dfa_active
+                             else {1: "lds_tile", 2: "lds_stream"}.get(int(info.scan_path), "generic"),
                 "roofline": {"kernel_ms": scan_ms, "achieved": alg / (scan_ms * 1e-3) / 1e9, "frac": alg / (scan_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "eval_kernels_ms": float(tm[:, 0].mean())},
                 "parity_checked": {"against": "oracle", "bytes": int(info.corpus_bytes), "exact": exact},
@@ -538,7 +539,9 @@ def main():
     if rank == 0:
         value = total_bytes_all * args.steps / elapsed / 1e9
         alg_bytes = int(info.corpus_bytes) + 8 * (V + 3)
-        if info.dfa_active:
+        if info.dfa_active and info.dfa_form == 2:  # (--vocab-file with a vocabulary whose prefixes are mostly not tokens)
+            scan_kernel, scan_name = "dfa_fscan_kernel<%d, false>" % info.dfa_chains, "lds_automaton_failure_form"
+        elif info.dfa_active:
             scan_kernel, scan_name = "dfa_scan_asm_kernel<%d>" % info.dfa_chains, "lds_automaton"
         else:
             scan_kernel = {1: "scan_tile_kernel", 2: "scan_ranges_kernel"}.get(int(info.scan_path), "scan_generic_kernel")

@@ -102,6 +102,8 @@ def test_deltas_on_cjk_and_many_moves(forced, monkeypatch):
     if forced:
         monkeypatch.setenv("TOKSCORE_DFA_MAX_COLD_PPM", "1000000")
         monkeypatch.setenv("TOKSCORE_DFA_MAX_VIRTUAL_PPM", "1000000")
+    else:  # (no automaton plan at all: the library would take the failure form for this vocabulary, and search with it)
+        monkeypatch.setenv("TOKSCORE_DFA_FORM", "1")
     corpus, off = synth.cjk_heavy(400_000, seed=9)
     tokens = synth.build_vocab(corpus[:200_000], 9000)
     V = len(tokens)
