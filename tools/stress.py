@@ -84,7 +84,7 @@ def big(name, config, tokens, corpus, off, sample_bytes=8_000_000):
            "total_tokens": int(tt), "set_corpus_s": t1 - t0, "first_evaluation_s": first_s,
            "eval_ms": tm[0], "scan_ms": tm[1], "fixup_ms": tm[2], "hist_reduce_ms": tm[3],
            "GBps_eval": tby / tm[0] / 1e6 if tm[0] else 0.0, "roofline_frac_scan": (tby / tm[1] / 1e6 / 8000.0) if tm[1] else 0.0,
-           "automaton_scan": int(info.dfa_active), "sample_bytes": int(off[d]), "sample_parity": sample_ok,
+           "automaton_scan": int(info.dfa_active), "automaton_form": {0: "none", 1: "flattened", 2: "failure"}[int(info.dfa_form)], "sample_bytes": int(off[d]), "sample_parity": sample_ok,
            "rare_token_rescored_chunks": resc, **props}
     s.close()
     print(json.dumps(rec), flush=True)
