@@ -111,6 +111,24 @@ def settle(scorer, out_ptr, stream_ptr, sync):
     return ms
 
 
+def spin_up(scorer, out_ptr, stream_ptr, sync, block=50, max_blocks=6):
+    """Untimed, before the warm-up steps: evaluations back to back in blocks of 50 until a block is no faster than the one
+    before it (1 %).  An idle MI355X takes some ten milliseconds of work to reach the clocks it then holds: the first
+    hundred 0.1 ms evaluations after a pause run 3 - 5 % slower than the next hundred (tools/dbg/ab_lib.py), and the
+    timed region is to measure the state a scoring loop is in, not the ramp.  -> ms per evaluation of each block."""
+    per = []
+    for _ in range(max_blocks):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(block):
+            scorer.score_async(out_ptr, stream_ptr)
+        sync()
+        per.append((time.perf_counter() - t0) * 1e3 / block)
+        if len(per) >= 2 and per[-1] > 0.99 * per[-2]:
+            break
+    return per
+
+
 def after_toggle(scorer, tokens, out_ptr, stream_ptr, sync):
     """What one toggle costs the next full evaluations (host clock, ms): the first ones run on the plan's own
     scan, then the automaton's image is rebuilt from the vocabulary as it is."""
@@ -368,6 +386,7 @@ def annealed_vocab_block(dev, args, synth, ta):
         out = torch.zeros(V + 5, dtype=torch.int64, device=dev)
         stream = torch.cuda.current_stream()
         settle(s, out.data_ptr(), stream.cuda_stream, torch.cuda.synchronize)
+        spin_up(s, out.data_ptr(), stream.cuda_stream, torch.cuda.synchronize, block=20, max_blocks=4)
         s.set_timing(1)
         s.drain_timings()
         n = max(3, args.steps // 2)
@@ -497,6 +516,7 @@ def main():
         torch.cuda.synchronize()
 
     settle_ms = settle(scorer, out.data_ptr(), stream.cuda_stream, sync)
+    spin_ms = spin_up(scorer, out.data_ptr(), stream.cuda_stream, sync)
     sample_every = 4 if args.steps >= 8 else 1
     scorer.set_timing(2, sample_every)
     elapsed = timed_steps(step, fence, args.steps, args.warmup, after_warmup=scorer.drain_timings)
@@ -586,6 +606,8 @@ def main():
             # stream image), the automaton's image and buffers, and the evaluations that still arrange things
             "plan_ms": {"set_corpus_host_ms": h2d_s * 1e3, "automaton_plan_ms": float(info.dfa_plan_ms), "automaton_image_build_ms": float(info.dfa_build_ms)},
             "first_evaluation_ms": settle_ms[0], "settling_evaluations_ms": settle_ms,
+            "spin_up": {"evaluations": 50 * len(spin_ms), "ms_per_evaluation_by_block_of_50": spin_ms,
+                        "note": "untimed, before the warm-up steps: until the device holds its clocks (a block no faster than the one before)"},
         }
         if world == 1 and not args.no_cpu:
             rec["two_evaluations_in_flight"] = two_in_flight(scorer, tokens, corpus, off, dev, args.steps)

@@ -73,6 +73,29 @@ __device__ __forceinline__ uint32_t dfa_key(const DfaDev &A, uint32_t S, uint32_
 	return b == A.cold_base ? G : b;
 }
 
+// The LDS array from its copy in global memory (every workgroup reads the same 160 KB: L2 after the first).  All of a
+// thread's loads are under way before its first store: one round trip instead of ten (a loop of load, wait, store
+// was 3 - 4 us of a 56 us scan; blockDim.x >= 1024 covers 40,832 slots with ten 16-byte loads per thread).
+__device__ __forceinline__ void dfa_fill_lds(const uint32_t *hot, uint32_t hot_slots, LDS_AS uint32_t *img) {
+	const u32x4 *src = reinterpret_cast<const u32x4 *>(hot); // (the array is padded to 16 bytes)
+	LDS_AS u32x4 *dst = (LDS_AS u32x4 *)img;
+	const uint32_t n = (hot_slots + 3) / 4;
+	constexpr int kInFlight = 10;
+	for (uint32_t base = threadIdx.x; base < n; base += kInFlight * blockDim.x) {
+		u32x4 v[kInFlight];
+#pragma unroll
+		for (int k = 0; k < kInFlight; k++) {
+			const uint32_t i = base + k * blockDim.x;
+			v[k] = src[i < n ? i : base];
+		}
+#pragma unroll
+		for (int k = 0; k < kInFlight; k++) {
+			const uint32_t i = base + k * blockDim.x;
+			if (i < n) dst[i] = v[k];
+		}
+	}
+}
+
 // The ranges transposed: 8-byte piece p of chain j of lane l of wave block wb at
 // ((wb * pieces + p) * C + j) * 64 + l (in pieces); range g = (wb * C + j) * 64 + l.
 __global__ void __launch_bounds__(256) dfa_transpose_kernel(const uint8_t *prep, uint64_t prep_total, uint32_t range_bytes,
@@ -159,11 +182,7 @@ __global__ void __launch_bounds__(1024) dfa_scan_kernel(DfaDev A, DfaWork W, Str
 	if (I.out) // (nothing else touches the output vector before this kernel has ended)
 		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < I.V + 5; i += gridDim.x * blockDim.x)
 			I.out[i] = i < 2 ? I.D : (i == I.V + 4 ? I.total_bytes : 0ull);
-	{
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(A.hot);
-		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)img;
-		for (uint32_t i = threadIdx.x; i < (A.hot_slots + 3) / 4; i += blockDim.x) dst[i] = src[i]; // (the array is padded to 16 bytes)
-	}
+	dfa_fill_lds(A.hot, A.hot_slots, img);
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = uni32(threadIdx.x >> 6);
@@ -251,11 +270,7 @@ __global__ void __launch_bounds__(1024) dfa_fscan_kernel(DfaDev A, DfaWork W, St
 	if (I.out) // (nothing else touches the output vector before this kernel has ended)
 		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < I.V + 5; i += gridDim.x * blockDim.x)
 			I.out[i] = i < 2 ? I.D : (i == I.V + 4 ? I.total_bytes : 0ull);
-	{
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(A.hot);
-		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)img;
-		for (uint32_t i = threadIdx.x; i < (A.hot_slots + 3) / 4; i += blockDim.x) dst[i] = src[i]; // (the array is padded to 16 bytes)
-	}
+	dfa_fill_lds(A.hot, A.hot_slots, img);
 	__syncthreads();
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t wave = uni32(threadIdx.x >> 6);
@@ -408,11 +423,7 @@ __global__ void __launch_bounds__(1024) dfa_scan_asm_kernel(DfaDev A, DfaWork W,
 	if (I.out) // (nothing else touches the output vector before this kernel has ended)
 		for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < I.V + 5; i += gridDim.x * blockDim.x)
 			I.out[i] = i < 2 ? I.D : (i == I.V + 4 ? I.total_bytes : 0ull);
-	{
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(A.hot);
-		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)img;
-		for (uint32_t i = threadIdx.x; i < (A.hot_slots + 3) / 4; i += blockDim.x) dst[i] = src[i];
-	}
+	dfa_fill_lds(A.hot, A.hot_slots, img);
 	__syncthreads();
 	if ((uint32_t)(uintptr_t)img != 0) {
 		// the loop takes 4 * slot index for an LDS address (the array starts at LDS address 0: this kernel
@@ -489,11 +500,7 @@ template <int C>
 __global__ void __launch_bounds__(1024) dfa_search_kernel(SearchDev A, DfaWork W, StreamDev Qa, const uint8_t *codes) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t dfa_search_smem[];
 	LDS_AS uint32_t *img = (LDS_AS uint32_t *)dfa_search_smem;
-	{
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(A.hot);
-		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)img;
-		for (uint32_t i = threadIdx.x; i < (A.hot_slots + 3) / 4; i += blockDim.x) dst[i] = src[i];
-	}
+	dfa_fill_lds(A.hot, A.hot_slots, img);
 	__syncthreads();
 	if ((uint32_t)(uintptr_t)img != 0) { // (as dfa_scan_asm_kernel: the loop takes 4 * slot index for an LDS address)
 		if (threadIdx.x == 0) Qa.cursor[1] = 1u;

@@ -964,6 +964,10 @@ DfaWork dfa_work(const tokscore_ctx *c) {
 	return W;
 }
 
+// The failure form's image takes a second of host time for a trie of millions of nodes, and with more than 16 trie nodes
+// per LDS slot its sample never kept 70 % of the lookups in LDS (config 4: 1.5 M nodes, 38 % beyond): not built then.
+bool fail_form_worth_a_try(const tokscore_ctx *c) { return c->trie.node_count() <= 16ull * dfa_lds_slots_max(c->dfa_lds_cap); }
+
 // Everything the automaton scan needs for the resident corpus and the vocabulary as it is; leaves
 // dfa_state at 1 (ready) or -1 (not for this vocabulary / corpus: the plan's scan serves every evaluation).
 void ensure_dfa(tokscore_ctx *c) {
@@ -974,7 +978,7 @@ void ensure_dfa(tokscore_ctx *c) {
 	const auto t0 = std::chrono::steady_clock::now();
 	c->dfa_fail = c->dfa_form_knob == 2;
 	if (!upload_dfa_image(c)) {
-		if (c->dfa_fail || c->dfa_form_knob == 1) return;
+		if (c->dfa_fail || c->dfa_form_knob == 1 || !fail_form_worth_a_try(c)) return;
 		c->dfa_fail = true; // (more virtual entries than the limit: the failure form has none)
 		if (!upload_dfa_image(c)) return;
 	}
@@ -987,7 +991,7 @@ void ensure_dfa(tokscore_ctx *c) {
 		const double steps = (double)std::max<uint64_t>(1, g.sample_steps);
 		const double limit_cold = (double)c->dfa_max_cold_ppm * 1e-6, limit_virtual = (double)c->dfa_max_virtual_ppm * 1e-6;
 		if (g.sample_steps != 0 && ((double)g.sample_cold / steps > limit_cold || (double)g.sample_virtual / steps > limit_virtual)) {
-			if (c->dfa_form_knob == 1) return;
+			if (c->dfa_form_knob == 1 || !fail_form_worth_a_try(c)) return;
 			c->dfa_fail = true;
 			if (!upload_dfa_image(c)) return;
 		}
