@@ -585,7 +585,7 @@ def main():
                                     "one full-vocabulary scoring pass, V=%d") % (args.mb, args.seed, V)
                                    + (", vocabulary from %s" % os.path.basename(args.vocab_file) if args.vocab_file else ""),
                        "docs_per_gpu": int(info.corpus_docs), "bytes_per_gpu": int(info.corpus_bytes),
-                       "vocab": V, "max_token_bytes": int(info.max_len), "trie_slots": int(info.trie_slots),
+                       "vocab": V, "max_token_bytes": int(info.max_len), "trie_nodes": int(info.trie_nodes), "trie_slots": int(info.trie_slots),
                        "trie_lds_slots": int(info.trie_lds_slots), "chunks": int(info.chunks),
                        "scan_path": scan_name,
                        "automaton": {"slots": int(info.dfa_slots), "virtual_slots": int(info.dfa_virtual_slots), "lds_slots": int(info.dfa_lds_slots),

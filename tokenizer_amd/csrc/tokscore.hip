@@ -375,6 +375,18 @@ int build_prepared(tokscore_ctx *c) {
 	return TOKSCORE_OK;
 }
 
+// TOKSCORE_TRACE_HOST=1: host milliseconds between marks, on stderr (where a first evaluation goes)
+struct HostTrace {
+	bool on = getenv("TOKSCORE_TRACE_HOST") != nullptr;
+	std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+	void mark(const char *what) {
+		if (!on) return;
+		const auto n = std::chrono::steady_clock::now();
+		fprintf(stderr, "tokscore: %-36s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+		t = n;
+	}
+};
+
 void free_dfa(tokscore_ctx *c) {
 	void **bufs[] = {(void **)&c->d_dhot, (void **)&c->d_dgof, (void **)&c->d_dslot, (void **)&c->d_dev_miss, (void **)&c->d_dev_arr, (void **)&c->d_dpool, (void **)&c->d_dcodes,
 	                 &c->d_dtcodes, (void **)&c->d_dstate, (void **)&c->d_dtag, (void **)&c->d_dcold, &c->d_dstream_m, &c->d_dstream_a,
@@ -509,7 +521,8 @@ int ensure_trie(tokscore_ctx *c) {
 		c->packed_valid = true;
 		c->device_trie_valid = false;
 		c->plan_valid = false;
-		c->dfa_invalid = true;
+		// (the automaton's image does not depend on the packing: set_vocab and set_corpus invalidate it themselves, and
+		// this may run after it was built -- the first toggle, move or count call after evaluations on the automaton)
 		c->simg_valid = c->trie.PackStream(&c->simg);
 	}
 	if (c->hostonly) return TOKSCORE_OK;
@@ -976,6 +989,7 @@ void ensure_dfa(tokscore_ctx *c) {
 	const uint64_t prep_total = c->total + c->D;
 	if (!c->dfa_enabled || c->force_generic || c->D == 0 || c->total == 0 || c->V + 5 >= 0x7FFFFFFFull || prep_total + kCorpusPad >= 0xFFFF0000ull) return;
 	const auto t0 = std::chrono::steady_clock::now();
+	HostTrace tr;
 	c->dfa_fail = c->dfa_form_knob == 2;
 	if (!upload_dfa_image(c)) {
 		if (c->dfa_fail || c->dfa_form_knob == 1 || !fail_form_worth_a_try(c)) return;
@@ -1000,6 +1014,7 @@ void ensure_dfa(tokscore_ctx *c) {
 		const DfaImage &g = c->dimg;
 		if (g.sample_steps != 0 && (double)g.sample_cold / (double)g.sample_steps > (double)c->dfa_fail_max_cold_ppm * 1e-6) return;
 	}
+	tr.mark("ensure_dfa: image(s) built + uploaded");
 	DfaScanPlan &P = c->dplan;
 	// (the failure form waits for the global array in most steps: four ranges per lane share each wait)
 	if (!plan_dfa_scan(c->dimg.hot_slots, prep_total, (uint32_t)c->num_cus, c->dfa_fail && c->dfa_chains == 0 ? 4 : c->dfa_chains, &P)) return;
@@ -1030,6 +1045,7 @@ void ensure_dfa(tokscore_ctx *c) {
 	     hipMemsetAsync(c->d_dtag, 0, nranges * sizeof(uint32_t), c->stream) == hipSuccess &&
 	     hipMemsetAsync(c->d_dcold, 0, (3 * (size_t)ncold + 3) * sizeof(uint32_t), c->stream) == hipSuccess &&
 	     hipMemsetAsync(c->d_dcursor, 0, 16 * sizeof(uint32_t), c->stream) == hipSuccess;
+	tr.mark("ensure_dfa: buffers allocated");
 	if (ok) {
 		CorpusDev C{c->d_bytes, c->d_off, c->D, c->total};
 		ByteCodes M;
@@ -1044,6 +1060,7 @@ void ensure_dfa(tokscore_ctx *c) {
 		     hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
 	}
 	if (d_flags) (void)hipFree(d_flags);
+	tr.mark("ensure_dfa: corpus prepared (synced)");
 	if (!ok || flags != 0) { // (flags: a document holds a NUL byte -- the separator's code inside a document)
 		(void)hipGetLastError();
 		free_dfa(c);
@@ -1158,8 +1175,9 @@ int fetch_out(tokscore_ctx *c, hipStream_t s) {
 
 // Enqueue one full evaluation into d_out (V+5 u64) on stream s.
 int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
-	int st = ensure_trie(c);
-	if (st) return st;
+	HostTrace tr;
+	int st = TOKSCORE_OK;
+	if (!c->vocab_set) return fail(c, TOKSCORE_E_STATE, "vocabulary not set");
 	if (!c->corpus_set) return fail(c, TOKSCORE_E_STATE, "corpus not set");
 	c->state_valid = false;
 	// the automaton scan, while its image is the vocabulary as it is; after toggles the plan's own scan
@@ -1170,6 +1188,7 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		c->dfa_invalid = false;
 	}
 	ensure_dfa(c);
+	tr.mark("enqueue_score: ensure_dfa");
 	bool use_dfa = c->dfa_state == 1 && c->dfa_enabled;
 	if (use_dfa && c->dfa_version != c->toggle_version) {
 		use_dfa = false;
@@ -1188,7 +1207,15 @@ int enqueue_score(tokscore_ctx *c, unsigned long long *d_out, hipStream_t s) {
 		}
 	}
 	if (use_dfa) c->dfa_evals++;
-	// the plan of the other scan paths: only when this evaluation runs on them (or a toggle / move / count call asks)
+	// The packed trie of the other scan paths (hotness sample, double array, stream image, their device copies: 100 ms
+	// of host time for the bench vocabulary) and their plan: only when this evaluation runs on them, or toggles wait
+	// to be applied to them -- the automaton is built from the trie itself.  Every other entry point that needs them
+	// (toggle, moves, counting, incremental re-scores, tokenize) asks for them itself.
+	if (!use_dfa || c->packed_valid) { // (once they exist they are kept up to date as ever: nothing to do when they are)
+		st = ensure_trie(c);
+		if (st) return st;
+		tr.mark("enqueue_score: ensure_trie");
+	}
 	if (!use_dfa) {
 		st = ensure_plan(c);
 		if (st) return st;
@@ -1835,10 +1862,13 @@ int tokscore_score(tokscore_ctx *c, uint64_t *counts, uint64_t *total_tokens, ui
 	(void)hipSetDevice(c->device);
 	int st = ensure_out(c);
 	if (st) return st;
+	HostTrace tr;
 	st = enqueue_score(c, c->d_out, c->stream);
 	if (st) return st;
+	tr.mark("tokscore_score: enqueued");
 	st = fetch_out(c, c->stream);
 	if (st) return st;
+	tr.mark("tokscore_score: result on the host");
 	const uint64_t *host = c->h_out;
 	st = check_overflow(c);
 	if (st == TOKSCORE_E_CAPACITY && !c->force_generic) {
