@@ -653,8 +653,10 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 	if (!c->simg_valid || c->total == 0) return TOKSCORE_OK;
 	StreamScanPlan sp;
 	if (!plan_stream_scan((uint32_t)c->simg.lt.size(), c->packed.max_len, (uint32_t)c->num_cus, &sp)) return TOKSCORE_OK;
+	HostTrace tr;
 	int st = build_prepared(c);
 	if (st || !c->prep_ok) return st;
+	tr.mark("plan_stream: prepared corpus");
 	uint64_t sbytes = env_u64("TOKSCORE_STREAM", 256);
 	sbytes = std::max<uint64_t>(sbytes, std::max<uint64_t>(64, 4 * c->packed.max_len));
 	const uint64_t spc = std::max<uint64_t>(1, std::min<uint64_t>(64, env_u64("TOKSCORE_SPC", 16)));
@@ -668,8 +670,10 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 	}
 	std::vector<uint32_t> syn;
 	const uint32_t window = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(sbytes - 1, 8192));
+	tr.mark("plan_stream: stream boundaries");
 	st = snap_boundaries(c, sb, window, syn);
 	if (st) return st;
+	tr.mark("plan_stream: boundaries snapped");
 	const size_t ns = sb.size() - 1;
 	size_t unsynced = 0;
 	for (size_t j = 1; j < ns; j++) unsynced += syn[j] ? 0 : 1;
@@ -714,6 +718,7 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 	cfirst.push_back((uint32_t)ns);
 	c->h_chunk_begin.push_back(c->total);
 	c->nchunks = (uint32_t)(c->h_chunk_begin.size() - 1);
+	tr.mark("plan_stream: offsets and chunks");
 	HIP_TRY(c, hipMalloc((void **)&c->d_chunk_first, cfirst.size() * sizeof(uint32_t)));
 	HIP_TRY(c, hipMemcpy(c->d_chunk_first, cfirst.data(), cfirst.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 	c->chunk_bytes = sbytes * spc;
@@ -753,6 +758,7 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 			c->rplan = sp;
 		}
 	}
+	tr.mark("plan_stream: ranges transposed");
 	HIP_TRY(c, hipMalloc((void **)&c->d_pbeg, (ns + 1) * sizeof(uint32_t)));
 	HIP_TRY(c, hipMemcpy(c->d_pbeg, pb.data(), (ns + 1) * sizeof(uint32_t), hipMemcpyHostToDevice));
 	{
@@ -765,9 +771,26 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 			}
 			fprintf(stderr, "plan_stream: %zu streams, longest %u bytes, %u over 1 KiB, %zu cuts dropped\n", ns, longest, over1k, unsynced);
 		}
+		// (by length in buckets, the longest first, streams of one length in corpus order: what a stable sort by
+		// descending length gives, without its second and a half per ten million streams)
 		std::vector<uint32_t> order(ns);
-		for (size_t j = 0; j < ns; j++) order[j] = (uint32_t)j;
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return pb[x + 1] - pb[x] > pb[y + 1] - pb[y]; });
+		{
+			constexpr uint32_t kCap = 1u << 16; // lengths from here on share the first bucket, sorted among themselves
+			std::vector<uint32_t> count(kCap + 2, 0), big;
+			auto len = [&](size_t j) { return pb[j + 1] - pb[j]; };
+			for (size_t j = 0; j < ns; j++) {
+				if (len(j) >= kCap) big.push_back((uint32_t)j);
+				else count[len(j)]++;
+			}
+			std::stable_sort(big.begin(), big.end(), [&](uint32_t x, uint32_t y) { return len(x) > len(y); });
+			std::copy(big.begin(), big.end(), order.begin());
+			size_t at = big.size();
+			std::vector<size_t> first(kCap, 0);
+			for (uint32_t l = kCap; l-- > 0;) first[l] = at, at += count[l];
+			for (size_t j = 0; j < ns; j++)
+				if (len(j) < kCap) order[first[len(j)]++] = (uint32_t)j;
+		}
+		tr.mark("plan_stream: streams by length");
 		HIP_TRY(c, hipMalloc((void **)&c->d_stream_order, std::max<size_t>(1, ns) * sizeof(uint32_t)));
 		HIP_TRY(c, hipMemcpy(c->d_stream_order, order.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice));
 	}
@@ -788,6 +811,7 @@ int plan_stream(tokscore_ctx *c, bool *ok) {
 	c->slab_blocks = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(16, c->total / (256 * 1024)));
 	c->slab_blocks = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(1, env_u64("TOKSCORE_SLAB_BLOCKS", c->slab_blocks)));
 	HIP_TRY(c, hipMalloc((void **)&c->d_slab, (size_t)c->slab_blocks * (c->simg.lt.size() + 1) * sizeof(uint32_t)));
+	tr.mark("plan_stream: buffers");
 	*ok = true;
 	return TOKSCORE_OK;
 }
