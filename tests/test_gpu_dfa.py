@@ -243,6 +243,34 @@ def test_cjk_vocabulary():
         s.close()
 
 
+def test_other_paths_trie_and_plan_are_built_on_demand():
+    # evaluations on the automaton need neither the packed trie of the other scan paths nor their plan (100 ms and
+    # 50 ms per GB of host time): both appear with the first call that does -- and change no result
+    corpus, off = synth.wiki_like(2_000_000, seed=26)
+    tokens = synth.build_vocab(corpus[:600_000], 6000)
+    voc = O.OracleVocab(*synth.pack_vocab(tokens))
+    s = ta.Scorer(0)
+    s.set_vocab(*synth.pack_vocab(tokens))
+    s.set_corpus(corpus, off)
+    _check(s, voc, corpus, off)
+    _check(s, voc, corpus, off)
+    info = s.info()
+    assert info.dfa_active == 1 and info.trie_slots == 0 and info.chunks == 0
+    multi = [i for i, t in enumerate(tokens) if len(t) > 2]
+    s.toggle(multi[7], False)
+    assert s.info().trie_slots > 0
+    voc2 = O.OracleVocab(*synth.pack_vocab([b"" if i == multi[7] else t for i, t in enumerate(tokens)]))
+    want = voc2.score(corpus, off, threads=8)
+    got = s.score(incremental=True)
+    assert got[1:] == want[1:] and np.array_equal(got[0], want[0])
+    assert s.info().chunks > 0
+    s.toggle(multi[7], True)
+    for _ in range(3):  # (the plan's scan, then the rebuilt image)
+        _check(s, voc, corpus, off)
+    assert s.info().dfa_active == 1
+    s.close()
+
+
 def test_async_evaluations_on_a_caller_stream():
     # (device memory and the stream through ctypes: torch's bundled HIP runtime must not be loaded second
     # into a process that already runs libtokscore.so's)
