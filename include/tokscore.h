@@ -162,8 +162,10 @@ int tokscore_count_occurrences(tokscore_ctx *ctx, uint32_t max_cp, uint64_t *cou
  * array in the library's device image, one copy per GPU, held until the process ends.
  *   - TOKSCORE_E_CAPACITY when 8 bytes per KiB of corpus plus one row (4 * (V + 4) bytes) exceed
  *     the 16 MiB; fewer rows than tokscore_count_occurrences would take only make it slower.
- *   - TOKSCORE_E_STATE until the context has run one evaluation (tokscore_count_occurrences or
- *     tokscore_score*): copying the trie to the device is set-up and allocates.  Also while toggles
+ *   - TOKSCORE_E_STATE until the packed trie is in device memory: copying it there is set-up and
+ *     allocates.  One tokscore_count_occurrences does it (so does any tokscore_toggle followed by an
+ *     evaluation, or an evaluation of a vocabulary the automaton scan does not serve; a tokscore_score
+ *     that the automaton scan serves does not: it needs no packed trie).  Also while toggles
  *     are pending (tokscore_toggle since the last evaluation): the next evaluation brings them to the
  *     device, this call changes nothing of the context's state.
  *   - Every call on a GPU, from any context, shares that GPU's array: two calls that overlap on

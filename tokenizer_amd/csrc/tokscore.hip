@@ -2477,7 +2477,7 @@ int tokscore_count_occurrences_static(tokscore_ctx *c, uint32_t max_cp, void *d_
 	// bringing the trie to the device allocates: that is set-up, done by any earlier evaluation
 	if (!c->packed_valid || !c->device_trie_valid)
 		return fail(c, TOKSCORE_E_STATE,
-		            "the trie is not in device memory yet: run tokscore_count_occurrences or tokscore_score once "
+		            "the trie is not in device memory yet: run tokscore_count_occurrences once "
 		            "before the first tokscore_count_occurrences_static");
 	hipStream_t s = stream ? (hipStream_t)stream : c->stream;
 	// Toggles since the last evaluation are patched into the device trie by the next evaluation, on the context's
