@@ -70,6 +70,24 @@ def test_automaton_matches_oracle_on_synthetic(kind, form):
     s.close()
 
 
+def test_failure_form_has_no_virtual_entries(monkeypatch):
+    # the vocabulary the reference's annealer wrote: 2.8 M virtual entries flattened, none in the failure form, whose
+    # rows hold the trie's own edges and at most one failure entry per state
+    g = O.load_golden("wiki_annealed")
+    corpus, off = synth.pack_docs(g["docs"])
+    s = _host_scorer(g["tokens"])
+    nodes = int(s.info().trie_nodes)
+    monkeypatch.setenv("TOKSCORE_HOSTDFA_FAIL", "0")
+    _, _, flat = s.hostdfa_check(corpus, off, max_slots=8 << 20)
+    monkeypatch.setenv("TOKSCORE_HOSTDFA_FAIL", "1")
+    counts, tt, fail = s.hostdfa_check(corpus, off, max_slots=8 << 20)
+    assert int(flat[2]) > 1_000_000 and int(fail[2]) == 0
+    assert nodes - 1 <= int(fail[1]) <= 2 * nodes + 256  # edges (+ the root row's entries for bytes without an edge) + failure entries
+    assert int(fail[0]) < int(flat[0]) // 8
+    assert tt == g["expected"]["total_tokens"] and np.array_equal(counts, g["expected"]["counts_vec"])
+    s.close()
+
+
 def test_automaton_refuses_what_it_cannot_hold():
     corpus, off = synth.random_utf8(300_000, seed=355)
     tokens = synth.sample_vocab(corpus, 4000, seed=355)
