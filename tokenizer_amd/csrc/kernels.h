@@ -302,6 +302,12 @@ uint64_t dfa_stream_capacity_batches(const DfaScanPlan &plan);
 void launch_dfa_transpose(const uint8_t *prep, uint64_t prep_total, uint32_t range_bytes, uint32_t chains, uint64_t nwb,
                           void *tcodes, hipStream_t stream);
 void launch_dfa_reset_states(const DfaWork &W, uint32_t start_word, hipStream_t stream);
+// After launch_dfa_reset_states, for a new image: every range's entry state from a walk over the `lookback` bytes in
+// front of the range (codes: the prepared corpus, linear), started in the separator's state.  A guess like the reset's,
+// only a far better one -- the automaton forgets where it started within a few tokens -- so the first evaluation's
+// fix-up finds most entries right instead of repairing every range (7 - 16 ms per image).  Nothing is counted.
+void launch_dfa_warm_entries(const DfaDev &A, const DfaWork &W, const uint8_t *codes, uint32_t start_word, uint32_t lookback,
+                             hipStream_t stream);
 // clears out (when given) and presets START / END / total_bytes; both streams' cursors = first_batches; changed[0..1] = 0
 void launch_dfa_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, const StreamDev &Qm,
                         const StreamDev &Qa, uint32_t first_batches, uint32_t *changed, hipStream_t stream);

@@ -1108,6 +1108,19 @@ __global__ void __launch_bounds__(1024) dfa_reduce_kernel(DfaDev A, const int16_
 
 __global__ void __launch_bounds__(256) dfa_fixup_kernel(DfaFix F) { dfa_fixup_body(F); }
 
+// kernels.h: launch_dfa_warm_entries.  One thread per range; the automaton from global memory, as the fix-up walks it,
+// with nothing booked (sign 0).
+__global__ void __launch_bounds__(256) dfa_warm_entries_kernel(DfaFix F, uint32_t start_word, uint32_t lookback) {
+	for (uint32_t g = 1 + blockIdx.x * blockDim.x + threadIdx.x; g < F.nranges; g += gridDim.x * blockDim.x) {
+		const uint64_t at = (uint64_t)g * F.range_bytes;
+		const uint64_t from = at > lookback ? at - lookback : 0;
+		uint32_t S = start_word & kStateMask, G = 0;
+		const uint8_t *p = F.codes + from;
+		for (uint32_t i = 0; i < (uint32_t)(at - from); i++) dfa_step_global(F, S, G, p[i], 0);
+		F.entry[g] = uint2{S & kStateMask, G};
+	}
+}
+
 // The counters of the global array's keys through the event tables, for the failure form: there a few percent of
 // an evaluation's events are counted under such keys (a state entered through an entry LDS does not hold), by a
 // hundred thousand counters whose events name the same few thousand ids -- booked one by one (dfa_reduce_kernel's
@@ -1171,6 +1184,15 @@ void launch_dfa_reset_states(const DfaWork &W, uint32_t start_word, hipStream_t 
 	if (W.nranges == 0) return;
 	hipLaunchKernelGGL(dfa_reset_states_kernel, dim3(std::min<uint32_t>((W.nranges + 255) / 256, 1024)), dim3(256), 0, stream,
 	                   W.entry, W.nranges, start_word);
+}
+
+void launch_dfa_warm_entries(const DfaDev &A, const DfaWork &W, const uint8_t *codes, uint32_t start_word, uint32_t lookback,
+                             hipStream_t stream) {
+	if (W.nranges < 2 || lookback == 0) return;
+	DfaFix F{};
+	F.A = A, F.codes = codes, F.range_bytes = W.range_bytes, F.nranges = W.nranges, F.entry = W.entry;
+	hipLaunchKernelGGL(dfa_warm_entries_kernel, dim3(std::min<uint32_t>((W.nranges + 255) / 256, 4096)), dim3(256), 0, stream, F, start_word,
+	                   lookback);
 }
 
 void launch_dfa_prepare(unsigned long long *out, uint32_t V, uint64_t D, uint64_t total_bytes, const StreamDev &Qm,

@@ -267,6 +267,7 @@ struct tokscore_ctx {
 	// failure form whatever the vocabulary.
 	uint64_t dfa_fail_max_cold_ppm = 300000; // (measured: wiki_annealed 0.18 - 0.28 wins over the tile scan, random UTF-8 V = 128 k 0.38 loses)
 	uint32_t dfa_form_knob = 0;
+	uint32_t dfa_warm_bytes = 64;  // TOKSCORE_DFA_WARM: bytes in front of a range that its first entry state is worked out from (0: the separator's state)
 	bool dfa_fail = false;         // the image is in the failure form
 	DfaScanPlan dplan = {};
 	uint32_t *d_dhot = nullptr, *d_dgof = nullptr, *d_dslot = nullptr, *d_dev_miss = nullptr, *d_dev_arr = nullptr, *d_dpool = nullptr;
@@ -1077,6 +1078,7 @@ void ensure_dfa(tokscore_ctx *c) {
 		launch_prep_corpus(C, M, c->d_dcodes, prep_total, d_flags, c->stream);
 		launch_dfa_transpose(c->d_dcodes, prep_total, P.range_bytes, P.chains, P.nwb, c->d_dtcodes, c->stream);
 		launch_dfa_reset_states(dfa_work(c), c->dimg.start_word(), c->stream);
+		launch_dfa_warm_entries(dfa_dev(c), dfa_work(c), c->d_dcodes, c->dimg.start_word(), c->dfa_warm_bytes, c->stream);
 		launch_dfa_prepare(nullptr, (uint32_t)c->V, c->D, c->total, StreamDev{c->d_dstream_m, (uint32_t)cap, c->d_dfill_m, c->d_dcursor},
 		                   StreamDev{c->d_dstream_a, (uint32_t)cap, c->d_dfill_a, c->d_dcursor + 4}, P.blocks * P.waves_per_block,
 		                   c->d_dcursor + 8, c->stream);
@@ -1124,6 +1126,7 @@ bool rebuild_dfa(tokscore_ctx *c) {
 		return false;
 	}
 	launch_dfa_reset_states(dfa_work(c), c->dimg.start_word(), c->stream);
+	launch_dfa_warm_entries(dfa_dev(c), dfa_work(c), c->d_dcodes, c->dimg.start_word(), c->dfa_warm_bytes, c->stream);
 	c->dfa_version = c->toggle_version;
 	c->dfa_stale_evals = 0;
 	c->dfa_epoch = 0;
@@ -1657,6 +1660,7 @@ int tokscore_create(tokscore_ctx **out, int device) {
 	c->dfa_max_virtual_ppm = env_u64("TOKSCORE_DFA_MAX_VIRTUAL_PPM", c->dfa_max_virtual_ppm);
 	c->dfa_fail_max_cold_ppm = env_u64("TOKSCORE_DFA_FAIL_MAX_COLD_PPM", c->dfa_fail_max_cold_ppm);
 	c->dfa_form_knob = (uint32_t)env_u64("TOKSCORE_DFA_FORM", 0);
+	c->dfa_warm_bytes = (uint32_t)std::min<uint64_t>(4096, env_u64("TOKSCORE_DFA_WARM", c->dfa_warm_bytes));
 	c->timing_on = env_u64("TOKSCORE_TIMING", 1) != 0;
 	c->timing_detail = env_u64("TOKSCORE_TIMING", 1) >= 2;
 	hipDeviceProp_t prop;
