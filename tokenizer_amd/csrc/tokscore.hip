@@ -512,19 +512,23 @@ StreamWork stream_work(const tokscore_ctx *c, bool selected) {
 
 int ensure_trie(tokscore_ctx *c) {
 	if (!c->vocab_set) return fail(c, TOKSCORE_E_STATE, "vocabulary not set");
+	HostTrace tr;
 	if (!c->packed_valid || (!c->sample_used && !c->sample.empty())) {
 		if (!c->sample.empty() && !c->sample_used) {
 			c->trie.AddHotnessSample(c->sample.data(), c->sample.size());
 			c->sample_used = true;
+			tr.mark("ensure_trie: hotness sample");
 		}
 		std::string e;
 		if (!c->trie.Pack(&c->packed, &e)) return fail(c, TOKSCORE_E_VOCAB, e);
+		tr.mark("ensure_trie: double array packed");
 		c->packed_valid = true;
 		c->device_trie_valid = false;
 		c->plan_valid = false;
 		// (the automaton's image does not depend on the packing: set_vocab and set_corpus invalidate it themselves, and
 		// this may run after it was built -- the first toggle, move or count call after evaluations on the automaton)
 		c->simg_valid = c->trie.PackStream(&c->simg);
+		tr.mark("ensure_trie: stream image packed");
 	}
 	if (c->hostonly) return TOKSCORE_OK;
 	if (!c->device_trie_valid && c->simg_valid) {
