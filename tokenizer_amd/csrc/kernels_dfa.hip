@@ -1126,19 +1126,24 @@ __global__ void __launch_bounds__(256) dfa_warm_entries_kernel(DfaFix F, uint32_
 // hundred thousand counters whose events name the same few thousand ids -- booked one by one (dfa_reduce_kernel's
 // last workgroups) they queue on those ids' words, 0.34 ms per evaluation.  Here a workgroup adds its counters'
 // events up in LDS bins over the ids first and books every id once.
-__global__ void __launch_bounds__(1024) dfa_reduce_cold_kernel(DfaDev A, uint32_t *cold_miss, uint32_t *cold_arr, uint32_t n_ids,
-                                                               unsigned long long *out, uint32_t total_index) {
+// Vocabularies of more ids than LDS has bins for take one launch per range of ids [id_lo, id_lo + n_ids): every launch
+// reads all the counters, the last one (`clear`) zeroes them.
+__global__ void __launch_bounds__(1024) dfa_reduce_cold_kernel(DfaDev A, uint32_t *cold_miss, uint32_t *cold_arr, uint32_t id_lo, uint32_t n_ids,
+                                                               uint32_t clear, unsigned long long *out, uint32_t total_index) {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cold_bins[];
 	for (uint32_t i = threadIdx.x; i < n_ids; i += blockDim.x) cold_bins[i] = 0;
 	__syncthreads();
+	auto add1 = [&](uint32_t id, uint32_t n) {
+		if (id - id_lo < n_ids) atomicAdd(&cold_bins[id - id_lo], n); // (unsigned: ids below id_lo wrap beyond n_ids)
+	};
 	auto add = [&](uint32_t ev, uint32_t n) {
 		if (ev == kEvNone) return;
 		if (!(ev & kEvList)) {
-			atomicAdd(&cold_bins[ev], n);
+			add1(ev, n);
 			return;
 		}
 		const uint32_t o = ev & ~kEvList, len = A.pool[o];
-		for (uint32_t i = 0; i < len; i++) atomicAdd(&cold_bins[A.pool[o + 1 + i]], n);
+		for (uint32_t i = 0; i < len; i++) add1(A.pool[o + 1 + i], n);
 	};
 	// counters [0, nslots - hot_slots): the global array's keys hot_slots + i; behind them the sums of the LDS keys
 	// that dfa_reduce_kernel left there
@@ -1148,11 +1153,11 @@ __global__ void __launch_bounds__(1024) dfa_reduce_cold_kernel(DfaDev A, uint32_
 		const uint32_t key = i < n_cold ? A.hot_slots + i : i - n_cold;
 		if (m) {
 			add(A.ev_miss[key], m);
-			cold_miss[i] = 0;
+			if (clear) cold_miss[i] = 0;
 		}
 		if (a) {
 			add(A.ev_arr[key], a);
-			cold_arr[i] = 0;
+			if (clear) cold_arr[i] = 0;
 		}
 	}
 	__syncthreads();
@@ -1160,7 +1165,7 @@ __global__ void __launch_bounds__(1024) dfa_reduce_cold_kernel(DfaDev A, uint32_
 	for (uint32_t i = threadIdx.x; i < n_ids; i += blockDim.x) {
 		const uint32_t v = cold_bins[i];
 		if (v) {
-			atomicAdd(&out[i], (unsigned long long)v);
+			atomicAdd(&out[id_lo + i], (unsigned long long)v);
 			mine += v;
 		}
 	}
@@ -1272,16 +1277,20 @@ void launch_dfa_count(const DfaDev &A, const DfaWork &W, const StreamDev &Qm, co
 	const uint32_t colgroups = (A.hot_slots + 127) / 128;
 	const uint32_t ncold = A.nslots - A.hot_slots;
 	// (the failure form counts a share of its events under keys of the global array: a launch of its own adds them up in LDS first)
-	const bool cold_apart = A.fail_code != 0 && ncold != 0 && (uint64_t)total_index * 4 <= 150u * 1024;
+	const bool cold_apart = A.fail_code != 0 && ncold != 0;
 	const uint32_t coldblocks = cold_apart ? 0u : std::min<uint32_t>((ncold + 1023) / 1024, 256);
 	hipLaunchKernelGGL(dfa_reduce_kernel, dim3(colgroups + coldblocks), dim3(64 * kDfaReduceGroups), 0, stream, A, rows, miss_blocks,
 	                   miss_blocks + arrival_blocks, colgroups, W.cold_miss, W.cold_arr, Qm, Qa, first_batches, changed, out, total_index,
 	                   cold_apart ? 1u : 0u);
 	if (cold_apart) {
-		const uint32_t lds_cold = total_index * 4;
-		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dfa_reduce_cold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cold);
-		hipLaunchKernelGGL(dfa_reduce_cold_kernel, dim3(std::min<uint32_t>((A.nslots + 4095) / 4096, 64)), dim3(1024), lds_cold, stream, A, W.cold_miss,
-		                   W.cold_arr, total_index, out, total_index);
+		constexpr uint32_t kIdsPerLaunch = 38400; // bins of a launch: 150 KB of LDS
+		const uint32_t per = std::min<uint32_t>(total_index, kIdsPerLaunch);
+		(void)hipFuncSetAttribute(reinterpret_cast<const void *>(&dfa_reduce_cold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(per * 4));
+		for (uint32_t lo = 0; lo < total_index; lo += per) {
+			const uint32_t n = std::min<uint32_t>(per, total_index - lo);
+			hipLaunchKernelGGL(dfa_reduce_cold_kernel, dim3(std::min<uint32_t>((A.nslots + 4095) / 4096, 64)), dim3(1024), per * 4, stream, A,
+			                   W.cold_miss, W.cold_arr, lo, n, lo + n >= total_index ? 1u : 0u, out, total_index);
+		}
 	}
 }
 
