@@ -285,6 +285,7 @@ struct SearchItems {
 	const uint32_t *pbeg;      // [nstreams + 1] stream boundaries (prepared offsets)
 	const uint32_t *block_stream; // [prep_total / 256 + 1] the stream that holds prepared offset 256 b
 	uint32_t nstreams;
+	uint32_t prep_total;       // bytes of the prepared corpus (`starts` has no bits from there on)
 };
 // block_stream from pbeg (once per plan)
 void launch_stream_blocks(const uint32_t *pbeg, uint32_t nstreams, uint32_t prep_total, uint32_t *block_stream, hipStream_t stream);

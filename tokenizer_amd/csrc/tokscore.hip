@@ -2188,8 +2188,8 @@ int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s
 	const size_t words = list_at + img.out_list.size() + 4;
 	for (;;) {
 		uint64_t slots = 1024;
-		// (a move's string sits on a token start in a few thousand of a 100 MB shard's streams: four slots per item)
-		const uint64_t want = c->sr_slots_fixed ? c->sr_slots_hint : std::max<uint64_t>(c->sr_slots_hint, (uint64_t)n * (c->prep_total / 8192 + 1024));
+		// (a move's string is the token taken in about a thousand of a 100 MB shard's streams: four slots per item and more)
+		const uint64_t want = c->sr_slots_fixed ? c->sr_slots_hint : std::max<uint64_t>(c->sr_slots_hint, (uint64_t)n * (c->prep_total / 32768 + 1024));
 		while (slots < want) slots <<= 1;
 		if (slots > (1ull << 28)) return 1;
 		const uint32_t list_cap = (uint32_t)(slots / 32); // (items <= slots / 2 in a table that is not full, spread evenly over the lists: four times their share)
@@ -2221,7 +2221,7 @@ int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s
 		DfaWork Wd = dfa_work(c);
 		const StreamDev Q{c->d_dstream_a, c->dstream_cap, c->d_dfill_a, d + cursor_at};
 		uint32_t *list_index = reinterpret_cast<uint32_t *>(items + slots);
-		SearchItems H{keys, count, items, (uint32_t)(slots - 1), d + flags_at, list_index, d + lists_at, list_cap, c->d_tok_starts, c->d_pbeg, c->d_block_stream, c->nstreams};
+		SearchItems H{keys, count, items, (uint32_t)(slots - 1), d + flags_at, list_index, d + lists_at, list_cap, c->d_tok_starts, c->d_pbeg, c->d_block_stream, c->nstreams, (uint32_t)c->prep_total};
 		launch_dfa_search(A, Wd, Q, c->d_dcodes, P, s);
 		launch_search_items(A, Q, H, (uint32_t)c->num_cus, s);
 		StreamWork W = stream_work(c, false);
