@@ -266,13 +266,15 @@ def moves_per_sec(scorer, tokens, corpus, off):
         return len(which) / (time.perf_counter() - t0)
 
     # (iii) K = 64 independent moves judged by one tokscore_score_toggles call, none applied
-    batches = [rng.choice(multi, size=64, replace=False) for _ in range(6)]
-    scorer.score_toggles(batches[0], 0)  # (the first call's buffers; the occurrence index where the one-pass search does not serve)
+    small = len(corpus) <= 500_000_000  # (calls of a fraction of a millisecond: enough of them that the first ones' share is small)
+    batches = [rng.choice(multi, size=64, replace=False) for _ in range(25 if small else 6)]
+    for _ in range(3 if small else 1):  # (the first call's buffers; the occurrence index where the one-pass search does not serve)
+        scorer.score_toggles(batches[0], 0)
     t0 = time.perf_counter()
     deltas = [scorer.score_toggles(b, 0) for b in batches[1:]]
     batched = 64 * len(deltas) / (time.perf_counter() - t0)
     # ... and 256 per call: one pass of the search automaton over the corpus costs the same for any number of moves
-    big = [rng.choice(multi, size=256, replace=False) for _ in range(4)]
+    big = [rng.choice(multi, size=256, replace=False) for _ in range(13 if small else 4)]
     scorer.score_toggles(big[0], 0)
     t0 = time.perf_counter()
     big_deltas = [scorer.score_toggles(b, 0) for b in big[1:]]

@@ -481,6 +481,26 @@ __global__ void __launch_bounds__(1024) find_toggle_streams_kernel(ToggleBatch B
 }
 
 // ---- batched move evaluation: the walks ---------------------------------------------------------
+// n 16-byte pieces from global memory to LDS, by the whole workgroup: all of a thread's loads are under way before its
+// first store (a loop of load, wait, store is a round trip per 16 KB: 10 - 15 us of a call of 64 moves, whose kernels
+// each stage the trie image for a few dozen microseconds of work)
+__device__ __forceinline__ void fill_lds_16(const u32x4 *src, LDS_AS u32x4 *dst, uint32_t n) {
+	constexpr int kInFlight = 8;
+	for (uint32_t base = threadIdx.x; base < n; base += kInFlight * blockDim.x) {
+		u32x4 v[kInFlight];
+#pragma unroll
+		for (int k = 0; k < kInFlight; k++) {
+			const uint32_t i = base + k * blockDim.x;
+			v[k] = src[i < n ? i : base];
+		}
+#pragma unroll
+		for (int k = 0; k < kInFlight; k++) {
+			const uint32_t i = base + k * blockDim.x;
+			if (i < n) dst[i] = v[k];
+		}
+	}
+}
+
 // The lookup loop of scan_stream_kernel, counting tokens per stream instead of logging them, with the
 // token-end bit of one slot flipped per lane (the move).  Without W.tg_items the items are all
 // streams and the counts go to W.tg_base (the vocabulary as it is: the context keeps them until a
@@ -503,12 +523,8 @@ __global__ void __launch_bounds__(1024) walk_toggles_kernel(StreamTrieDev T, Str
 	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
 	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
 	{
-		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
-		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
-		dst = (LDS_AS u32x4 *)(lds + label_bytes);
-		src = reinterpret_cast<const u32x4 *>(T.base);
-		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		fill_lds_16(reinterpret_cast<const u32x4 *>(T.lt), (LDS_AS u32x4 *)lds, label_bytes / 16);
+		fill_lds_16(reinterpret_cast<const u32x4 *>(T.base), (LDS_AS u32x4 *)(lds + label_bytes), info_bytes / 16);
 		if (threadIdx.x < kToggleLists) s_count[threadIdx.x] = listed ? min(W.tg_count[threadIdx.x], W.tg_cap) : 0u;
 	}
 	__syncthreads();
@@ -806,9 +822,19 @@ __device__ __forceinline__ uint32_t local_token(const LDS_AS uint8_t *l_lt, cons
                                                 uint32_t pos, uint32_t flip_slot, uint32_t &counts, const LDS_AS uint8_t *win, uint32_t win_at,
                                                 uint32_t window) {
 	uint32_t nb = 0, d = 0, len = 1, slot = 0;
+	uint32_t w4 = 0, w4_at = 0xFFFFFFFFu; // four bytes of the window at a time: one LDS round trip less on three steps of four
 	do {
 		const uint32_t rel = pos + d - win_at;
-		const uint32_t c = rel < window ? win[rel] : prep[pos + d];
+		uint32_t c;
+		if (rel < window) {
+			if ((rel & ~3u) != w4_at) {
+				w4_at = rel & ~3u;
+				w4 = *(const LDS_AS uint32_t *)(win + w4_at);
+			}
+			c = (w4 >> (8 * (rel & 3u))) & 0xFFu;
+		} else {
+			c = prep[pos + d];
+		}
 		const uint32_t t = nb + c;
 		uint32_t x = l_lt[t] ^ c;
 		if (t == flip_slot) x ^= 0x80u;
@@ -834,12 +860,8 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
 	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
 	{
-		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
-		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
-		dst = (LDS_AS u32x4 *)(lds + label_bytes);
-		src = reinterpret_cast<const u32x4 *>(T.base);
-		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		fill_lds_16(reinterpret_cast<const u32x4 *>(T.lt), (LDS_AS u32x4 *)lds, label_bytes / 16);
+		fill_lds_16(reinterpret_cast<const u32x4 *>(T.base), (LDS_AS u32x4 *)(lds + label_bytes), info_bytes / 16);
 		if (threadIdx.x < kToggleLists) s_count[threadIdx.x] = min(W.tg_count[threadIdx.x], W.tg_cap);
 	}
 	__syncthreads();
@@ -873,19 +895,67 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 						if (k < it.n && it.off[k] >= cur && it.off[k] < best) best = it.off[k];
 					if (best == 0xFFFFFFFFu) break;
 					uint32_t na = 0, nb2 = 0;
-					const uint32_t win_at = (beg + best) & ~15u;
-					{
+					uint32_t win_at = (beg + best) & ~15u;
+					auto load_window = [&]() {
 						const u32x4 *src = reinterpret_cast<const u32x4 *>(W.prep + win_at); // (the prepared corpus is padded)
 						LDS_AS u32x4 *dst = (LDS_AS u32x4 *)win;
 #pragma unroll
 						for (uint32_t k = 0; k < kLocalWindow / 16; k++)
 							if (k * 16 < window) dst[k] = src[k];
+					};
+					load_window();
+					if (W.tg_known) {
+						// The chain of the vocabulary as it is needs no walk: it stands where W.tg_known has a bit.  Only the
+						// chain with the move is walked, until it stands on one of those -- that is where the two meet -- and
+						// the difference is its steps minus the bits passed (separators are a step and a bit alike).
+						uint32_t bw = 0;
+						unsigned long long bits0 = 0, bits1 = 0; // the map from the window's first byte on (128 positions and more)
+						auto load_bits = [&]() {
+							bw = win_at >> 6;
+							bits0 = W.tg_known[bw];
+							bits1 = W.tg_known[bw + 1]; // (the map has a word to spare)
+						};
+						auto word = [&](uint32_t w) { return w == bw ? bits0 : w == bw + 1 ? bits1 : W.tg_known[w]; };
+						load_bits();
+						const uint32_t q0 = beg + best;
+						uint32_t pb = q0, steps = 0;
+						do {
+							if (window >= 32 && pb + 24 > win_at + window) {
+								win_at = pb & ~15u;
+								load_window();
+								load_bits();
+							}
+							uint32_t cnt = 0;
+							pb = local_token(l_lt, l_base, W.prep, pb, flip_slot, cnt, win, win_at, window);
+							steps++;
+						} while (pb < W.prep_total && !((word(pb >> 6) >> (pb & 63)) & 1ull));
+						uint32_t passed = 0; // bits in [q0, pb)
+						for (uint32_t w = q0 >> 6; w <= (pb - 1) >> 6; w++) {
+							unsigned long long x = word(w);
+							if (w == q0 >> 6) x &= ~0ull << (q0 & 63);
+							if (w == (pb - 1) >> 6) x &= ~0ull >> (63 - ((pb - 1) & 63));
+							passed += (uint32_t)__builtin_popcountll(x);
+						}
+						d += (int)steps - (int)passed;
+						cur = pb - beg;
+						continue;
 					}
+					// (one call per step, for whichever chain is behind: a branch per chain made every wave run both)
 					uint32_t pa = local_token(l_lt, l_base, W.prep, beg + best, 0xFFFFFFFFu, na, win, win_at, window);
-					uint32_t pb = local_token(l_lt, l_base, W.prep, beg + best, flip_slot, nb2, win, win_at, window);
+					uint32_t pb = beg + best;
 					while (pa != pb) {
-						if (pa < pb) pa = local_token(l_lt, l_base, W.prep, pa, 0xFFFFFFFFu, na, win, win_at, window);
-						else pb = local_token(l_lt, l_base, W.prep, pb, flip_slot, nb2, win, win_at, window);
+						const bool a = pa < pb;
+						const uint32_t p = a ? pa : pb;
+						// (the window follows the chain that is behind: a byte beyond it is a round trip to global memory of its
+						// own, and the walks that go on for a hundred bytes were what a wave waited for)
+						if (window >= 32 && p + 24 > win_at + window) {
+							win_at = p & ~15u;
+							load_window();
+						}
+						uint32_t cnt = 0;
+						const uint32_t r = local_token(l_lt, l_base, W.prep, p, a ? 0xFFFFFFFFu : flip_slot, cnt, win, win_at, window);
+						if (a) pa = r, na += cnt;
+						else pb = r, nb2 += cnt;
 					}
 					d += (int)nb2 - (int)na;
 					cur = pa - beg;

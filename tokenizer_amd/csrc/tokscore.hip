@@ -2232,6 +2232,7 @@ int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s
 		W.tg_n = count;
 		W.tg_moves = n;
 		W.tg_whole = c->knob_search_whole;
+		W.tg_known = getenv("TOKSCORE_LOCAL_BOTH") ? nullptr : c->d_tok_starts;
 		W.tg_slot = d + slots_at;
 		W.tg_base = c->d_stream_tokens;
 		W.tg_delta = reinterpret_cast<unsigned long long *>(d);
