@@ -899,9 +899,13 @@ __global__ void __launch_bounds__(1024) local_toggles_kernel(StreamTrieDev T, St
 					auto load_window = [&]() {
 						const u32x4 *src = reinterpret_cast<const u32x4 *>(W.prep + win_at); // (the prepared corpus is padded)
 						LDS_AS u32x4 *dst = (LDS_AS u32x4 *)win;
+						u32x4 v[kLocalWindow / 16]; // (all loads, then the stores: one round trip, not one per piece)
 #pragma unroll
 						for (uint32_t k = 0; k < kLocalWindow / 16; k++)
-							if (k * 16 < window) dst[k] = src[k];
+							if (k * 16 < window) v[k] = src[k];
+#pragma unroll
+						for (uint32_t k = 0; k < kLocalWindow / 16; k++)
+							if (k * 16 < window) dst[k] = v[k];
 					};
 					load_window();
 					if (W.tg_known) {
