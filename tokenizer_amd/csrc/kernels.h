@@ -119,6 +119,7 @@ struct StreamWork {
 	const ToggleItem *tg_items = nullptr;
 	uint32_t *tg_base = nullptr;        // [nstreams] tokens per stream under the vocabulary as it is
 	const uint32_t *tg_order = nullptr; // [nstreams] with tg_base: the streams by length, longest first (optional)
+	const uint32_t *block_stream = nullptr; // optional, [prep_total / 256 + 1]: the stream that holds prepared offset 256 b (launch_stream_blocks)
 	const unsigned long long *tg_known = nullptr; // local walks, optional: tg_starts of the vocabulary as it is (then only the chain with the move is walked)
 	unsigned long long *tg_starts = nullptr; // [prep_total / 64 + 1] written with tg_base (zeroed by the caller): bit q = a token of the vocabulary as it is starts at q
 	const uint32_t *tg_count = nullptr; // [kToggleLists] items appended per list (may exceed tg_cap: the surplus was not stored)

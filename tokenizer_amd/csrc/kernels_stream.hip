@@ -1281,12 +1281,8 @@ __global__ void __launch_bounds__(1024) mark_ranges_kernel(StreamTrieDev T, Stre
 	const uint32_t label_bytes = (T.nslots + 15) & ~15u;
 	const uint32_t info_bytes = (T.nslots * 2 + 15) & ~15u;
 	{
-		LDS_AS u32x4 *dst = (LDS_AS u32x4 *)lds;
-		const u32x4 *src = reinterpret_cast<const u32x4 *>(T.lt);
-		for (uint32_t i = threadIdx.x; i < label_bytes / 16; i += blockDim.x) dst[i] = src[i];
-		dst = (LDS_AS u32x4 *)(lds + label_bytes);
-		src = reinterpret_cast<const u32x4 *>(T.base);
-		for (uint32_t i = threadIdx.x; i < info_bytes / 16; i += blockDim.x) dst[i] = src[i];
+		fill_lds_16(reinterpret_cast<const u32x4 *>(T.lt), (LDS_AS u32x4 *)lds, label_bytes / 16);
+		fill_lds_16(reinterpret_cast<const u32x4 *>(T.base), (LDS_AS u32x4 *)(lds + label_bytes), info_bytes / 16);
 	}
 	__syncthreads();
 	const LDS_AS uint8_t *l_lt = (const LDS_AS uint8_t *)lds;
@@ -1331,10 +1327,15 @@ __global__ void __launch_bounds__(1024) mark_ranges_kernel(StreamTrieDev T, Stre
 			}
 			const uint32_t q = b0 + cp;
 			uint32_t l = 0, h = W.nstreams; // last stream with pbeg <= q (pbeg[0] = 0)
-			while (h - l > 1) {
-				const uint32_t mid = (l + h) >> 1;
-				if (W.pbeg[mid] <= q) l = mid;
-				else h = mid;
+			if (W.block_stream) { // (a table of the stream at every 256th byte: two round trips instead of nineteen)
+				l = W.block_stream[q >> 8];
+				while (l + 1 < W.nstreams && W.pbeg[l + 1] <= q) l++;
+			} else {
+				while (h - l > 1) {
+					const uint32_t mid = (l + h) >> 1;
+					if (W.pbeg[mid] <= q) l = mid;
+					else h = mid;
+				}
 			}
 			sidx = l;
 			cut = W.pbeg[sidx + 1];

@@ -2144,6 +2144,14 @@ int score_toggles_by_search(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hi
 	return TOKSCORE_OK;
 }
 
+// the stream at every 256th prepared byte (once per stream plan)
+int ensure_block_stream(tokscore_ctx *c, hipStream_t s) {
+	if (c->d_block_stream) return TOKSCORE_OK;
+	HIP_TRY(c, hipMalloc((void **)&c->d_block_stream, ((size_t)c->prep_total / 256 + 2) * sizeof(uint32_t)));
+	launch_stream_blocks(c->d_pbeg, c->nstreams, (uint32_t)c->prep_total, c->d_block_stream, s);
+	return TOKSCORE_OK;
+}
+
 int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s, int64_t *deltas) {
 	if (!c->knob_search || n == 0 || n >= 0x10000u) return 1;
 	if (c->dfa_invalid) { // (as enqueue_score: the corpus or the trie changed since the automaton's plan was made)
@@ -2174,9 +2182,9 @@ int search_batch(tokscore_ctx *c, const ToggleSpec *m, uint32_t n, hipStream_t s
 		if (e == hipSuccess) *cap = need;
 		return e;
 	};
-	if (!c->d_block_stream) {
-		HIP_TRY(c, hipMalloc((void **)&c->d_block_stream, ((size_t)c->prep_total / 256 + 2) * sizeof(uint32_t)));
-		launch_stream_blocks(c->d_pbeg, c->nstreams, (uint32_t)c->prep_total, c->d_block_stream, s);
+	{
+		const int st = ensure_block_stream(c, s);
+		if (st) return st;
 	}
 	const DfaScanPlan &P = c->dplan;
 	const uint32_t first_batches = P.blocks * P.waves_per_block;
@@ -2344,6 +2352,9 @@ int tokscore_score_toggles(tokscore_ctx *c, const uint64_t *token_index, const i
 		if (c->d_tprep && c->entries_epoch == c->trie_epoch && !c->knob_no_mark_ranges) {
 			// a full evaluation of this vocabulary has just left every range's true entry: walk the ranges
 			HIP_TRY(c, hipMemsetAsync(c->d_stream_tokens, 0, ((size_t)c->nstreams + 1) * sizeof(uint32_t), s));
+			st = ensure_block_stream(c, s);
+			if (st) return st;
+			Wb.block_stream = c->d_block_stream;
 			launch_mark_ranges(stream_trie_dev(c), Wb, c->rplan, s);
 		} else launch_count_streams(stream_trie_dev(c), Wb, c->splan, s);
 		HIP_TRY(c, hipGetLastError());
