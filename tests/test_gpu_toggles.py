@@ -266,3 +266,45 @@ def test_incremental_parity_under_the_default_cost_model_and_under_the_test_rule
             assert took_partial[0] and took_partial[2], "a token in a handful of chunks: the partial passes were expected"
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("both", [False, True])
+def test_moves_on_repetitive_text(both, monkeypatch):
+    """Three letters, strings that overlap themselves: occurrences of a move's string inside the stretch an earlier
+    one changed, walks that go on for dozens of tokens, occurrences that begin a longer token (dropped before the table),
+    and the string as the corpus' last bytes (the token-start map has no bit behind them).  both: the chain of the
+    vocabulary as it is walked as well, instead of read from the map."""
+    if both:
+        monkeypatch.setenv("TOKSCORE_LOCAL_BOTH", "1")
+    rng = np.random.default_rng(11)
+    docs = []
+    for _ in range(400):
+        n = int(rng.integers(20, 1500))
+        runs = []
+        while sum(len(r) for r in runs) < n:
+            unit = [b"ab", b"aba", b"abc", b"c", b"ba", b"bab", b"abab", b"cab"][int(rng.integers(0, 8))]
+            runs.append(unit * int(rng.integers(1, 12)))
+        docs.append(b"".join(runs)[:n])
+    docs.append(b"cabcababab" * 3 + b"abab")     # ends with strings of the vocabulary
+    corpus = np.frombuffer(b"".join(docs), dtype=np.uint8).copy()
+    off = np.zeros(len(docs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(d) for d in docs])
+    tokens = [b"a", b"b", b"c", b"ab", b"ba", b"aba", b"bab", b"abab", b"abc", b"ca", b"cab", b"bc", b"ababab", b"cc", b"bca"]
+    V = len(tokens)
+    s = ta.Scorer(0)
+    try:
+        s.set_vocab(*synth.pack_vocab(tokens))
+        s.set_corpus(corpus, off)
+        s.score()
+        enabled = np.ones(V, dtype=bool)
+        idx = list(range(3, V))
+        _check_moves(s, tokens, enabled, corpus, off, idx, [0] * len(idx))
+        assert s.info().search_passes > 0, "the one-pass search served the call"
+        for i in (5, 7, 10):                      # "aba", "abab", "cab" off: moves that enable, moves against a changed vocabulary
+            s.toggle(i, False)
+            enabled[i] = False
+        s.score()
+        got = _check_moves(s, tokens, enabled, corpus, off, idx, [0 if enabled[i] else 1 for i in idx])
+        assert any(int(d) != 0 for d in got)
+    finally:
+        s.close()
