@@ -34,7 +34,8 @@ def _check_moves(s, tokens, enabled, corpus, off, idx, en):
 @pytest.mark.parametrize("env", [{}, {"TOKSCORE_SEARCH": "0"},
                                  {"TOKSCORE_SEARCH": "0", "TOKSCORE_TOGGLE_ITEMS": "2000", "TOKSCORE_TOGGLE_LIST": "4"}, {"TOKSCORE_SCAN": "tile"},
                                  {"TOKSCORE_NOMARKRANGES": "1"}, {"TOKSCORE_SEARCH_SLOTS": "1024"}, {"TOKSCORE_SEARCH_MOVES": "3"},
-                                 {"TOKSCORE_DFA_CHAINS": "1"}, {"TOKSCORE_DFA_CHAINS": "4"}, {"TOKSCORE_LOCAL_BOTH": "1"}])
+                                 {"TOKSCORE_DFA_CHAINS": "1"}, {"TOKSCORE_DFA_CHAINS": "4"}, {"TOKSCORE_LOCAL_BOTH": "1"},
+                                 {"TOKSCORE_DFA_FORM": "2"}])
 def test_deltas_equal_oracle_differences(env, monkeypatch):
     """env: the moves' strings found by one pass of a search automaton over the corpus (the default where the
     automaton scan has a plan) / through the occurrence index and a search per (move, chunk): one batch / several
@@ -42,7 +43,8 @@ def test_deltas_equal_oracle_differences(env, monkeypatch):
     move-by-move fallback on a scan path without the batched kernel / token starts and tokens per stream always
     from the walk over streams (after a full evaluation they come from its ranges otherwise) / the search's
     (move, stream) table too small at first / three moves per pass / the search loop for 1 and 4 ranges per lane / both chains walked (by default the
-    chain of the vocabulary as it is comes from the token-start map)."""
+    chain of the vocabulary as it is comes from the token-start map) / full evaluations on the automaton's failure
+    form (the search runs on that plan's transposed corpus, four ranges per lane)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     corpus, off = synth.wiki_like(1_500_000, seed=31)
